@@ -1,0 +1,140 @@
+/* libzkpoa_prover.so -- C ABI of the MI355X (gfx950) Groth16 prover for zk-proof-of-assets.
+ *
+ * Drop-in boundary. The reference has an EXEC boundary, not an FFI:
+ *   scripts/g16_prove.sh:248-252   "$rapidsnark_path" zkey witness.wtns proof.json public.json
+ *   scripts/g16_prove.sh:255-259   npx snarkjs groth16 prove   (same four positional arguments)
+ * The `prover` executable built from this library takes exactly that argv. The library
+ * entry points below are what an FFI binding for the same step would bind; the first two
+ * mirror iden3/rapidsnark's prover.h (the C API of the binary the reference execs), the
+ * zkpoa_* ones expose the stages of the path for device-resident use and for parity tests.
+ *
+ * Conventions: plain C types, caller-allocated buffers, no global state except what hangs
+ * off a zkpoa_context. All byte formats are the reference's wire formats:
+ *   Fq/Fr element : 32 bytes little-endian
+ *   G1 point      : 64 bytes  = x||y, affine, Montgomery form (R = 2^256), infinity = zeros
+ *   G2 point      : 128 bytes = x.c0||x.c1||y.c0||y.c1, same conventions
+ *   scalar        : 32 bytes little-endian, standard (non-Montgomery) form, < r
+ * exactly as in .zkey sections 5-9 and .wtns section 2.
+ *
+ * The compute path is HIP-only: every function that needs the GPU fails with an error
+ * (never falls back to the CPU) when no gfx950 device is usable.
+ */
+#ifndef ZKPOA_PROVER_H
+#define ZKPOA_PROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes: same values as rapidsnark prover.h ---------------------------------- */
+#define PROVER_OK 0x0
+#define PROVER_ERROR 0x1
+#define PROVER_ERROR_SHORT_BUFFER 0x2
+#define PROVER_INVALID_WITNESS_LENGTH 0x3
+
+/* ---- one-shot prove: replaces the process exec'd at scripts/g16_prove.sh:248-252 -------- */
+/* zkey / wtns are complete file images. proof_buffer / public_buffer receive NUL-terminated
+ * JSON text; *proof_size / *public_size are in: capacity, out: bytes needed incl. NUL (also
+ * on PROVER_ERROR_SHORT_BUFFER). JSON style is rapidsnark's unless env ZKPOA_JSON=snarkjs.
+ * r, s come from /dev/urandom unless env ZKPOA_R / ZKPOA_S (decimal) are set. */
+int groth16_prover(const void* zkey_buffer, unsigned long zkey_size,
+                   const void* wtns_buffer, unsigned long wtns_size,
+                   char* proof_buffer, unsigned long* proof_size,
+                   char* public_buffer, unsigned long* public_size,
+                   char* error_msg, unsigned long error_msg_maxsize);
+
+/* Same, reading the zkey from a path (mmap) -- what the `prover` CLI uses. */
+int groth16_prover_zkey_file(const char* zkey_file_path,
+                             const void* wtns_buffer, unsigned long wtns_size,
+                             char* proof_buffer, unsigned long* proof_size,
+                             char* public_buffer, unsigned long* public_size,
+                             char* error_msg, unsigned long error_msg_maxsize);
+
+/* ---- context ----------------------------------------------------------------------------- */
+typedef struct zkpoa_context zkpoa_context;
+typedef struct zkpoa_zkey zkpoa_zkey;
+
+/* Creates a context on HIP device `device` (streams + workspace). Fails if no GPU. */
+int zkpoa_context_create(int device, zkpoa_context** ctx, char* error_msg, unsigned long error_msg_maxsize);
+void zkpoa_context_destroy(zkpoa_context* ctx);
+/* message of the last failing call on this context (valid until the next call) */
+const char* zkpoa_last_error(const zkpoa_context* ctx);
+
+/* ---- device-resident proving key: replaces snarkjs readSection(zkey, 4..9) per prove ------ */
+/* Parses the binfile container and uploads sections 4-9 to HBM once. */
+int zkpoa_zkey_load(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size, zkpoa_zkey** zkey);
+void zkpoa_zkey_free(zkpoa_context* ctx, zkpoa_zkey* zkey);
+/* header fields: out[0]=nVars, out[1]=nPublic, out[2]=domainSize, out[3]=nCoefs */
+int zkpoa_zkey_info(const zkpoa_zkey* zkey, uint64_t out[4]);
+
+/* Full prove against a resident key: groth16_prove.js steps 2-7.
+ * r_le / s_le: 32-byte little-endian standard-form scalars, or NULL for /dev/urandom.
+ * proof_points: 64 (pi_a) + 128 (pi_b) + 64 (pi_c) bytes, wire format above.
+ * public_le: nPublic * 32 bytes (w[1..nPublic], standard form). */
+int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey,
+                const void* wtns_buffer, unsigned long wtns_size,
+                const uint8_t* r_le, const uint8_t* s_le,
+                uint8_t proof_points[256], uint8_t* public_le, unsigned long public_capacity);
+
+/* proof_points / public -> JSON text. style 0 = rapidsnark bytes, 1 = snarkjs bytes
+ * (SURVEY.md 8a row a11). Size protocol as groth16_prover. */
+int zkpoa_proof_to_json(const uint8_t proof_points[256], int style, char* buffer, unsigned long* size);
+int zkpoa_public_to_json(const uint8_t* public_le, unsigned long n_public, int style, char* buffer,
+                         unsigned long* size);
+
+/* ---- stages of the path, host buffers in / out (upload + compute + download) -------------- */
+/* G1.multiExpAffine / G2.multiExpAffine (snarkjs groth16_prove.js; rapidsnark ParallelMultiexp) */
+int zkpoa_msm_g1(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[64]);
+int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[128]);
+/* Fr.fft / Fr.ifft: n = 2^log_n Montgomery-form elements, natural order in and out, in place */
+int zkpoa_ntt(zkpoa_context* ctx, void* data, unsigned log_n, int inverse);
+/* The H-scalar chain: buildABC1 + 3 x (ifft, batchApplyKey(inc), fft) + joinABC. coeffs is the
+ * payload of zkey section 4 (u32 nCoefs, then 44-byte records), witness n_vars x 32 B;
+ * out = domain_size x 32 B standard form. */
+int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned long coeffs_size, const void* witness,
+                    uint64_t n_vars, unsigned log_domain, void* out);
+
+/* ---- same stages on device-resident data (what bench.py times; pointers are HIP device ptrs) */
+int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t out[64]);
+int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t out[128]);
+int zkpoa_ntt_device(zkpoa_context* ctx, void* d_data, unsigned log_n, int inverse);
+
+/* Synthetic bases for benchmarks at sizes where no CPU generator is affordable:
+ * P_i = (a + i*b) * G, i in [i0, i0+n), written affine/Montgomery into d_out (n*64 or n*128 B).
+ * a_le, b_le: 32-byte LE standard-form scalars. Known discrete logs make an O(n) field-only
+ * check of any MSM result possible. */
+int zkpoa_gen_bases_g1_device(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0,
+                              uint64_t n, void* d_out);
+int zkpoa_gen_bases_g2_device(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0,
+                              uint64_t n, void* d_out);
+
+/* Sum of affine points (the "all-reduce of partial sums" step of a sharded MSM, done on the host:
+ * SURVEY.md 8e). in: count x 64/128 B, out: 64/128 B. No GPU needed. */
+int zkpoa_g1_sum(const void* points, uint64_t count, uint8_t out[64]);
+int zkpoa_g2_sum(const void* points, uint64_t count, uint8_t out[128]);
+/* k * P on the host (used to check known-dlog MSM results). */
+int zkpoa_g1_mul(const uint8_t point[64], const uint8_t scalar_le[32], uint8_t out[64]);
+int zkpoa_g2_mul(const uint8_t point[128], const uint8_t scalar_le[32], uint8_t out[128]);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Timings (ms, HIP events on the stream that ran the kernels) of the last call on this context.
+ * id: 0 = whole device part of last MSM, 1 = its bucket-accumulation kernel (dominant kernel),
+ *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total.
+ * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto). */
+float zkpoa_last_ms(const zkpoa_context* ctx, int id);
+int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value);
+
+/* ---- element-wise device hooks used by the parity tests ----------------------------------- */
+/* field: 0 = Fq, 1 = Fr. op: 0 = Montgomery mul, 1 = add, 2 = sub, 3 = inverse (b ignored),
+ * 4 = to Montgomery, 5 = from Montgomery. a, b, out: n x 32 B host buffers. */
+int zkpoa_field_op(zkpoa_context* ctx, int field, int op, const void* a, const void* b, void* out, uint64_t n);
+/* group: 1 = G1, 2 = G2. out[i] = a[i] + b[i] (affine in, affine out, all exceptional cases). */
+int zkpoa_group_add(zkpoa_context* ctx, int group, const void* a, const void* b, void* out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKPOA_PROVER_H */

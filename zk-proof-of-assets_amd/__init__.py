@@ -1,0 +1,330 @@
+"""zkpoa_amd -- Python host layer over libzkpoa_prover.so (the MI355X Groth16 prover).
+
+Mirrors the reference's interface for the prove step: the reference calls an external prover
+as `prover <zkey> <wtns> <proof.json> <public.json>` (scripts/g16_prove.sh:248-252) or
+`snarkjs groth16 prove` with the same four arguments (scripts/g16_prove.sh:255-259); here
+that is `groth16_prove(zkey_path, wtns_path, proof_path, public_path)`, plus the stages of
+the path (`msm_g1`, `msm_g2`, `ntt`, `h_scalars`) as the C ABI exposes them.
+
+This package never computes on the CPU: if the shared library is missing, or no HIP device
+is usable, calls raise. (The directory name has a hyphen, so the package is loaded through
+`__graft_entry__.load_package()` / tests/conftest.py under the module name `zkpoa_amd`.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkpoa_prover.so")
+PROVER_BIN = os.path.join(_HERE, "prover")
+
+PROVER_OK = 0
+PROVER_ERROR = 1
+PROVER_ERROR_SHORT_BUFFER = 2
+PROVER_INVALID_WITNESS_LENGTH = 3
+
+# every symbol include/zkpoa_prover.h declares
+EXPORTS = [
+    "groth16_prover", "groth16_prover_zkey_file",
+    "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
+    "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
+    "zkpoa_proof_to_json", "zkpoa_public_to_json",
+    "zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_ntt", "zkpoa_h_scalars",
+    "zkpoa_msm_g1_device", "zkpoa_msm_g2_device", "zkpoa_ntt_device",
+    "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
+    "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
+    "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
+]
+
+
+class ZkpoaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkpoaError("libzkpoa_prover.so not built (%s): run `python -c 'import __graft_entry__ as g; "
+                             "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+        ul_p = ctypes.POINTER(ctypes.c_ulong)
+        L.zkpoa_context_create.argtypes = [ctypes.c_int, c_void_pp, ctypes.c_char_p, ctypes.c_ulong]
+        L.zkpoa_context_destroy.argtypes = [ctypes.c_void_p]
+        L.zkpoa_context_destroy.restype = None
+        L.zkpoa_last_error.argtypes = [ctypes.c_void_p]
+        L.zkpoa_last_error.restype = ctypes.c_char_p
+        L.zkpoa_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.zkpoa_last_ms.restype = ctypes.c_float
+        L.zkpoa_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]
+        for name in ("zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_msm_g1_device", "zkpoa_msm_g2_device"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                         ctypes.c_void_p]
+        L.zkpoa_ntt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
+        L.zkpoa_ntt_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
+        L.zkpoa_h_scalars.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p]
+        for name in ("zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64,
+                                         ctypes.c_uint64, ctypes.c_void_p]
+        for name in ("zkpoa_g1_sum", "zkpoa_g2_sum"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        for name in ("zkpoa_g1_mul", "zkpoa_g2_mul"):
+            getattr(L, name).argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
+        L.zkpoa_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_uint64]
+        L.zkpoa_group_add.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_uint64]
+        L.zkpoa_zkey_load.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, c_void_pp]
+        L.zkpoa_zkey_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_zkey_free.restype = None
+        L.zkpoa_zkey_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.zkpoa_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
+                                  ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
+        L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
+        L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
+                                     ctypes.c_void_p, ul_p, ctypes.c_void_p, ul_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.groth16_prover_zkey_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_ulong,
+                                               ctypes.c_void_p, ul_p, ctypes.c_void_p, ul_p, ctypes.c_void_p,
+                                               ctypes.c_ulong]
+        _lib = L
+    return _lib
+
+
+def _buf(b):
+    """bytes-like -> (ctypes pointer, keepalive)."""
+    if isinstance(b, (bytes, bytearray)):
+        arr = (ctypes.c_char * len(b)).from_buffer_copy(b) if isinstance(b, bytes) else (ctypes.c_char * len(b)).from_buffer(b)
+        return ctypes.cast(arr, ctypes.c_void_p), arr
+    # numpy array or anything exposing the buffer protocol
+    mv = memoryview(b)
+    arr = (ctypes.c_char * mv.nbytes).from_buffer(b) if not mv.readonly else (ctypes.c_char * mv.nbytes).from_buffer_copy(mv.tobytes())
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+class Context:
+    """A device context (one GPU). Raises if no HIP device is usable."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = lib().zkpoa_context_create(device, ctypes.byref(self._h), err, 512)
+        if rc != PROVER_OK:
+            self._h = None
+            raise ZkpoaError("zkpoa_context_create: " + err.value.decode())
+
+    def close(self):
+        if self._h:
+            lib().zkpoa_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != PROVER_OK:
+            raise ZkpoaError("%s failed (%d): %s" % (what, rc, lib().zkpoa_last_error(self._h).decode()))
+
+    def set_option(self, key, value):
+        self._check(lib().zkpoa_set_option(self._h, key.encode(), int(value)), "zkpoa_set_option")
+
+    def last_ms(self, ident):
+        return float(lib().zkpoa_last_ms(self._h, ident))
+
+    # ---- stages, host buffers -------------------------------------------------------------
+    def msm_g1(self, bases, scalars, n=None):
+        n = len(scalars) // 32 if n is None else n
+        pb, kb = _buf(bases)
+        ps, ks = _buf(scalars)
+        out = ctypes.create_string_buffer(64)
+        self._check(lib().zkpoa_msm_g1(self._h, pb, ps, n, out), "zkpoa_msm_g1")
+        return out.raw
+
+    def msm_g2(self, bases, scalars, n=None):
+        n = len(scalars) // 32 if n is None else n
+        pb, kb = _buf(bases)
+        ps, ks = _buf(scalars)
+        out = ctypes.create_string_buffer(128)
+        self._check(lib().zkpoa_msm_g2(self._h, pb, ps, n, out), "zkpoa_msm_g2")
+        return out.raw
+
+    def ntt(self, data, log_n, inverse=False):
+        buf = bytearray(data)
+        p, k = _buf(buf)
+        self._check(lib().zkpoa_ntt(self._h, p, log_n, 1 if inverse else 0), "zkpoa_ntt")
+        return bytes(buf)
+
+    def h_scalars(self, coeffs_section, witness, n_vars, log_domain):
+        pc, kc = _buf(coeffs_section)
+        pw, kw = _buf(witness)
+        out = ctypes.create_string_buffer(32 << log_domain)
+        self._check(lib().zkpoa_h_scalars(self._h, pc, len(coeffs_section), pw, n_vars, log_domain, out),
+                    "zkpoa_h_scalars")
+        return out.raw
+
+    # ---- stages, device pointers (ints) ---------------------------------------------------
+    def msm_g1_device(self, d_bases, d_scalars, n):
+        out = ctypes.create_string_buffer(64)
+        self._check(lib().zkpoa_msm_g1_device(self._h, d_bases, d_scalars, n, out), "zkpoa_msm_g1_device")
+        return out.raw
+
+    def msm_g2_device(self, d_bases, d_scalars, n):
+        out = ctypes.create_string_buffer(128)
+        self._check(lib().zkpoa_msm_g2_device(self._h, d_bases, d_scalars, n, out), "zkpoa_msm_g2_device")
+        return out.raw
+
+    def ntt_device(self, d_data, log_n, inverse=False):
+        self._check(lib().zkpoa_ntt_device(self._h, d_data, log_n, 1 if inverse else 0), "zkpoa_ntt_device")
+
+    def gen_bases_g1_device(self, a, b, i0, n, d_out):
+        self._check(lib().zkpoa_gen_bases_g1_device(self._h, int(a).to_bytes(32, "little"),
+                                                    int(b).to_bytes(32, "little"), i0, n, d_out),
+                    "zkpoa_gen_bases_g1_device")
+
+    def gen_bases_g2_device(self, a, b, i0, n, d_out):
+        self._check(lib().zkpoa_gen_bases_g2_device(self._h, int(a).to_bytes(32, "little"),
+                                                    int(b).to_bytes(32, "little"), i0, n, d_out),
+                    "zkpoa_gen_bases_g2_device")
+
+    # ---- element-wise hooks ------------------------------------------------------------------
+    def field_op(self, field, op, a, b=None):
+        n = len(a) // 32
+        pa, ka = _buf(a)
+        pb, kb = _buf(b) if b is not None else (None, None)
+        out = ctypes.create_string_buffer(max(1, 32 * n))
+        self._check(lib().zkpoa_field_op(self._h, field, op, pa, pb, out, n), "zkpoa_field_op")
+        return out.raw[:32 * n]
+
+    def group_add(self, group, a, b):
+        size = 64 if group == 1 else 128
+        n = len(a) // size
+        pa, ka = _buf(a)
+        pb, kb = _buf(b)
+        out = ctypes.create_string_buffer(max(1, size * n))
+        self._check(lib().zkpoa_group_add(self._h, group, pa, pb, out, n), "zkpoa_group_add")
+        return out.raw[:size * n]
+
+    # ---- proving key + prove -----------------------------------------------------------------
+    def load_zkey(self, zkey_bytes):
+        return ZKey(self, zkey_bytes)
+
+    def prove(self, zkey, wtns_bytes, r=None, s=None):
+        """-> (proof_points[256 bytes], public[nPublic*32 bytes])"""
+        pw, kw = _buf(wtns_bytes)
+        rb = None if r is None else int(r).to_bytes(32, "little")
+        sb = None if s is None else int(s).to_bytes(32, "little")
+        proof = ctypes.create_string_buffer(256)
+        npub = zkey.info()[1]
+        pub = ctypes.create_string_buffer(max(1, 32 * npub))
+        rc = lib().zkpoa_prove(self._h, zkey._h, pw, len(wtns_bytes), rb, sb, proof, pub, 32 * npub)
+        self._check(rc, "zkpoa_prove")
+        return proof.raw, pub.raw[:32 * npub]
+
+
+class ZKey:
+    """A proving key resident in HBM (zkey sections 4-9 uploaded once)."""
+
+    def __init__(self, ctx, zkey_bytes):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        p, k = _buf(zkey_bytes)
+        ctx._check(lib().zkpoa_zkey_load(ctx._h, p, len(zkey_bytes), ctypes.byref(self._h)), "zkpoa_zkey_load")
+
+    def info(self):
+        out = (ctypes.c_uint64 * 4)()
+        lib().zkpoa_zkey_info(self._h, out)
+        return tuple(int(v) for v in out)
+
+    def close(self):
+        if self._h and self._ctx._h:
+            lib().zkpoa_zkey_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _json_call(fn, *args):
+    size = ctypes.c_ulong(0)
+    rc = fn(*args, None, ctypes.byref(size))
+    if rc not in (PROVER_OK, PROVER_ERROR_SHORT_BUFFER):
+        raise ZkpoaError("json conversion failed")
+    buf = ctypes.create_string_buffer(size.value)
+    rc = fn(*args, buf, ctypes.byref(size))
+    if rc != PROVER_OK:
+        raise ZkpoaError("json conversion failed")
+    return buf.value.decode()
+
+
+def proof_to_json(proof_points, style="rapidsnark"):
+    p, k = _buf(proof_points)
+    return _json_call(lib().zkpoa_proof_to_json, p, 0 if style == "rapidsnark" else 1)
+
+
+def public_to_json(public_le, style="rapidsnark"):
+    p, k = _buf(public_le if len(public_le) else b"\0")
+    return _json_call(lib().zkpoa_public_to_json, p, len(public_le) // 32, 0 if style == "rapidsnark" else 1)
+
+
+def g1_sum(points):
+    p, k = _buf(points)
+    out = ctypes.create_string_buffer(64)
+    lib().zkpoa_g1_sum(p, len(points) // 64, out)
+    return out.raw
+
+
+def g2_sum(points):
+    p, k = _buf(points)
+    out = ctypes.create_string_buffer(128)
+    lib().zkpoa_g2_sum(p, len(points) // 128, out)
+    return out.raw
+
+
+def g1_mul(point, k):
+    out = ctypes.create_string_buffer(64)
+    lib().zkpoa_g1_mul(point, int(k).to_bytes(32, "little"), out)
+    return out.raw
+
+
+def g2_mul(point, k):
+    out = ctypes.create_string_buffer(128)
+    lib().zkpoa_g2_mul(point, int(k).to_bytes(32, "little"), out)
+    return out.raw
+
+
+def groth16_prove(zkey_path, wtns_path, proof_path, public_path):
+    """The reference's prove step (scripts/g16_prove.sh:248-252) through the C ABI:
+    same four arguments as the `prover` executable."""
+    with open(wtns_path, "rb") as f:
+        wtns = f.read()
+    pw, kw = _buf(wtns)
+    psz = ctypes.c_ulong(1 << 12)
+    usz = ctypes.c_ulong(1 << 20)
+    proof = ctypes.create_string_buffer(psz.value)
+    public = ctypes.create_string_buffer(usz.value)
+    err = ctypes.create_string_buffer(1024)
+    rc = lib().groth16_prover_zkey_file(os.fsencode(zkey_path), pw, len(wtns), proof, ctypes.byref(psz), public,
+                                        ctypes.byref(usz), err, 1024)
+    if rc == PROVER_ERROR_SHORT_BUFFER:
+        proof = ctypes.create_string_buffer(psz.value)
+        public = ctypes.create_string_buffer(usz.value)
+        rc = lib().groth16_prover_zkey_file(os.fsencode(zkey_path), pw, len(wtns), proof, ctypes.byref(psz), public,
+                                            ctypes.byref(usz), err, 1024)
+    if rc != PROVER_OK:
+        raise ZkpoaError("groth16_prover failed (%d): %s" % (rc, err.value.decode()))
+    for path, text in ((proof_path, proof.value), (public_path, public.value)):
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(text)
+        os.replace(tmp, path)

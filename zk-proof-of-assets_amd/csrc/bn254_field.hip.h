@@ -1,0 +1,279 @@
+// BN254 prime-field arithmetic for gfx950 (CDNA4): Fq (base field) and Fr (scalar field).
+//
+// Replaces, on the device, the field layer the reference's external provers use
+// (rapidsnark fq.asm/fr.asm, ffjavascript WasmField1 -- SURVEY.md 8a row a4): 254-bit primes,
+// elements stored as 4 x u64 little-endian (= 8 x u32 here), Montgomery radix R = 2^256.
+//
+// CDNA4 has no 64x64 multiplier; the widest integer multiply is v_mad_u64_u32
+// (32x32 + 64 -> 64, with carry-out). So "4-limb 64-bit" is the storage layout and the
+// arithmetic is 8 x 32-bit limbs: product-scanning (column-wise) Montgomery multiplication,
+// each product = one v_mad_u64_u32 into a 64-bit column accumulator + one v_addc into the
+// third accumulator word.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zkpoa {
+
+#define ZK_DEV __device__ __forceinline__
+
+struct FqParams {
+  // q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+  static constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
+  // R mod q
+  static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                      0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  // R^2 mod q
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+};
+
+struct FrParams {
+  // r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+  static constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
+  static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                      0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+};
+
+// ---- carry helpers ---------------------------------------------------------------------------
+ZK_DEV uint32_t addc(uint32_t a, uint32_t b, uint32_t& carry) {
+  uint32_t co;
+  uint32_t r = __builtin_addc(a, b, carry, &co);
+  carry = co;
+  return r;
+}
+ZK_DEV uint32_t subb(uint32_t a, uint32_t b, uint32_t& borrow) {
+  uint32_t bo;
+  uint32_t r = __builtin_subc(a, b, borrow, &bo);
+  borrow = bo;
+  return r;
+}
+
+// acc (96 bit: lo64 + hi32) += a * b
+ZK_DEV void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo), "+v"(hi)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+
+template <class PRM>
+struct Fp {
+  uint32_t l[8];
+
+  static ZK_DEV Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+  }
+  static ZK_DEV Fp one() {  // Montgomery form of 1
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = PRM::ONE[i];
+    return r;
+  }
+  static ZK_DEV Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = PRM::R2[i];
+    return r;
+  }
+  ZK_DEV bool is_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i];
+    return o == 0;
+  }
+  ZK_DEV bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= (l[i] ^ b.l[i]);
+    return o == 0;
+  }
+  ZK_DEV bool operator!=(const Fp& b) const { return !(*this == b); }
+
+  // r = (a >= p) ? a - p : a     (a < 2p)
+  static ZK_DEV Fp reduce_once(const Fp& a) {
+    Fp d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.l[i] = subb(a.l[i], PRM::P[i], bw);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = bw ? a.l[i] : d.l[i];
+    return r;
+  }
+
+  friend ZK_DEV Fp operator+(const Fp& a, const Fp& b) {
+    Fp s;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.l[i] = addc(a.l[i], b.l[i], c);
+    // p < 2^254 so a+b < 2^255: no carry out of the top limb
+    return reduce_once(s);
+  }
+  friend ZK_DEV Fp operator-(const Fp& a, const Fp& b) {
+    Fp d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.l[i] = subb(a.l[i], b.l[i], bw);
+    uint32_t mask = 0u - bw;
+    uint32_t c = 0;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = addc(d.l[i], PRM::P[i] & mask, c);
+    return r;
+  }
+  ZK_DEV Fp neg() const {
+    if (is_zero()) return *this;
+    Fp r;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = subb(PRM::P[i], l[i], bw);
+    return r;
+  }
+  ZK_DEV Fp dbl() const { return *this + *this; }
+
+  // Montgomery product a*b/R mod p, finely-integrated product scanning.
+  friend ZK_DEV Fp operator*(const Fp& a, const Fp& b) {
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    uint32_t m[8];
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) mac96(lo, hi, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96(lo, hi, m[i], PRM::P[k - i]);
+      m[k] = (uint32_t)lo * PRM::INV;
+      mac96(lo, hi, m[k], PRM::P[0]);
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96(lo, hi, a.l[i], b.l[k - i]);
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96(lo, hi, m[i], PRM::P[k - i]);
+      r.l[k - 8] = (uint32_t)lo;
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+    return reduce_once(r);
+  }
+  ZK_DEV Fp sqr() const { return (*this) * (*this); }
+
+  // standard form <-> Montgomery form
+  ZK_DEV Fp to_mont() const { return (*this) * r2(); }
+  ZK_DEV Fp from_mont() const {
+    Fp o = zero();
+    o.l[0] = 1;
+    return (*this) * o;
+  }
+
+  // a^(p-2); exponent p-2 taken from PRM::P (rarely used on device: batch inversions)
+  ZK_DEV Fp inv() const {
+    Fp res = one();
+    Fp base = *this;
+    // e = p - 2
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = PRM::P[i];
+    e[0] -= 2;  // P[0] >= 2 for both primes
+    for (int i = 0; i < 8; i++) {
+      uint32_t w = e[i];
+      for (int bit = 0; bit < 32; bit++) {
+        if (w & 1) res = res * base;
+        base = base.sqr();
+        w >>= 1;
+      }
+    }
+    return res;
+  }
+};
+
+using Fq = Fp<FqParams>;
+using Fr = Fp<FrParams>;
+
+// ---- Fq2 = Fq[u]/(u^2+1) ---------------------------------------------------------------------
+struct Fq2 {
+  Fq c0, c1;
+  static ZK_DEV Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+  static ZK_DEV Fq2 one() { return {Fq::one(), Fq::zero()}; }
+  ZK_DEV bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  ZK_DEV bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  ZK_DEV bool operator!=(const Fq2& b) const { return !(*this == b); }
+  friend ZK_DEV Fq2 operator+(const Fq2& a, const Fq2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  friend ZK_DEV Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+  ZK_DEV Fq2 neg() const { return {c0.neg(), c1.neg()}; }
+  ZK_DEV Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+  // Karatsuba: 3 Fq multiplications
+  friend ZK_DEV Fq2 operator*(const Fq2& a, const Fq2& b) {
+    Fq t0 = a.c0 * b.c0;
+    Fq t1 = a.c1 * b.c1;
+    Fq t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
+    return {t0 - t1, t2 - t0 - t1};
+  }
+  // (a0+a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u
+  ZK_DEV Fq2 sqr() const {
+    Fq t = c0 * c1;
+    return {(c0 + c1) * (c0 - c1), t + t};
+  }
+  ZK_DEV Fq2 inv() const {
+    Fq d = (c0.sqr() + c1.sqr()).inv();
+    return {c0 * d, (c1 * d).neg()};
+  }
+};
+
+template <class F>
+struct FieldBytes;
+template <>
+struct FieldBytes<Fq> { static constexpr int N = 32; };
+template <>
+struct FieldBytes<Fr> { static constexpr int N = 32; };
+template <>
+struct FieldBytes<Fq2> { static constexpr int N = 64; };
+
+// 16-byte vector loads/stores of field elements (coalescing sweet spot: 16 B per lane-instruction)
+template <class PRM>
+ZK_DEV Fp<PRM> load_fp(const void* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fp<PRM> r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+template <class PRM>
+ZK_DEV void store_fp(void* p, const Fp<PRM>& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+ZK_DEV Fq2 load_fq2(const void* p) {
+  return {load_fp<FqParams>(p), load_fp<FqParams>(reinterpret_cast<const char*>(p) + 32)};
+}
+ZK_DEV void store_fq2(void* p, const Fq2& v) {
+  store_fp<FqParams>(p, v.c0);
+  store_fp<FqParams>(reinterpret_cast<char*>(p) + 32, v.c1);
+}
+
+template <class F> ZK_DEV F load_field(const void* p);
+template <> ZK_DEV Fq load_field<Fq>(const void* p) { return load_fp<FqParams>(p); }
+template <> ZK_DEV Fr load_field<Fr>(const void* p) { return load_fp<FrParams>(p); }
+template <> ZK_DEV Fq2 load_field<Fq2>(const void* p) { return load_fq2(p); }
+ZK_DEV void store_field(void* p, const Fq& v) { store_fp<FqParams>(p, v); }
+ZK_DEV void store_field(void* p, const Fr& v) { store_fp<FrParams>(p, v); }
+ZK_DEV void store_field(void* p, const Fq2& v) { store_fq2(p, v); }
+
+}  // namespace zkpoa

@@ -1,0 +1,110 @@
+// Device context shared by the MSM / NTT / ABC stages: one HIP device, a set of streams, and a
+// grow-only workspace arena per stream so that no hipMalloc happens inside a timed step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace zkpoa {
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+
+#define ZK_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      throw ::zkpoa::HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + \
+                              __FILE__ + ":" + std::to_string(__LINE__));                         \
+  } while (0)
+
+// Grow-only bump arena. reset() rewinds; take() never frees, it reallocates when too small
+// (only legal while nothing is in flight on the owning stream -> callers reserve() up front).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (base) ZK_HIP(hipFree(base));
+    base = nullptr;
+    ZK_HIP(hipMalloc(&base, bytes));
+    cap = bytes;
+  }
+  void reset() { off = 0; }
+  template <class T>
+  T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+    if (off + bytes > cap) throw HipError("arena overflow (reserve() too small)");
+    T* p = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return p;
+  }
+  void release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = off = 0;
+  }
+};
+
+struct Lane {  // one stream + its workspace + a pinned host staging area for small read-backs
+  hipStream_t stream = nullptr;
+  Arena ws;
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void init() {
+    ZK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    pinned_cap = 1 << 20;
+    ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
+    ZK_HIP(hipEventCreate(&ev0));
+    ZK_HIP(hipEventCreate(&ev1));
+  }
+  void destroy() {
+    ws.release();
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    pinned = nullptr;
+    stream = nullptr;
+    ev0 = ev1 = nullptr;
+  }
+};
+
+struct DeviceCtx {
+  int device = 0;
+  int num_cu = 256;
+  static constexpr int kLanes = 6;
+  Lane lanes[kLanes];
+  bool ok = false;
+  // last-run kernel timing (HIP events on the lane's stream), for bench.py's roofline object
+  float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  void init(int dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw HipError("zkpoa: no HIP device visible (the MSM/NTT path is HIP-only; there is no CPU fallback)");
+    if (dev < 0 || dev >= count) throw HipError("zkpoa: device index out of range");
+    device = dev;
+    ZK_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    ZK_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cu = prop.multiProcessorCount;
+    for (auto& l : lanes) l.init();
+    ok = true;
+  }
+  void destroy() {
+    if (!ok) return;
+    (void)hipSetDevice(device);
+    for (auto& l : lanes) l.destroy();
+    ok = false;
+  }
+};
+
+}  // namespace zkpoa

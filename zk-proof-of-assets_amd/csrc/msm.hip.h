@@ -1,0 +1,549 @@
+// Pippenger multi-scalar multiplication over BN254 G1 / G2 for gfx950, generic over the
+// coordinate field F (Fq -> G1, Fq2 -> G2).
+//
+// Replaces G1.multiExpAffine / G2.multiExpAffine of snarkjs (groth16_prove.js, five call sites:
+// SURVEY.md 3.2 step 5) and rapidsnark's ParallelMultiexp, the step
+// that runs behind the reference call site scripts/g16_prove.sh:248-252.
+//
+// Inputs are exactly the reference's wire formats: bases affine / Montgomery / 64 B (G1) or
+// 128 B (G2) as in .zkey sections 5-9, scalars 32 B little-endian standard form as in .wtns.
+//
+// Pipeline (all kernels on one stream; one 8-byte read-back to size the launches):
+//   1 count    : scalar -> sign-normalised (s > r/2 -> r-s, negate base) signed c-bit digits;
+//                per-(window,bucket) histogram with global atomics; the dominant hot bucket of
+//                real witnesses (|digit| = 1, i.e. scalars 0/1/-1) is aggregated per wavefront
+//                with a 64-bit ballot so it costs one atomic per wave, not one per lane.
+//   2 scan     : exclusive scan of the histogram (bucket offsets) + piece offsets.
+//   3 scatter  : counting sort of point indices by (window,bucket) using the ranks from 1.
+//   4 accumulate (level 0): buckets are cut into pieces of <= K0 entries; one thread sums one
+//                piece with XYZZ mixed additions (gather of 64/128-B affine bases). Pieces make
+//                the work per thread bounded whatever the scalar distribution; buckets with
+//                more than one piece are finished by further levels over the partial sums.
+//   5 reduce   : sum_b b*B[b] per window: threads take 8-bucket segments (running sums), weight
+//                them by the segment index, then an LDS tree sums segments per window.
+//   6 host     : W window sums -> Horner over 2^c on the host (O(W*c) group ops).
+#pragma once
+#include "bn254_ec.hip.h"
+#include "device_ctx.hpp"
+#include <string.h>
+#include <utility>
+
+namespace zkpoa {
+
+struct MsmPlan {
+  uint32_t n = 0;   // points
+  uint32_t c = 0;   // window bits
+  uint32_t W = 0;   // windows
+  uint32_t Nb = 0;  // buckets per window = 2^(c-1)
+  uint32_t TB = 0;  // total buckets
+  uint32_t K0 = 0;  // level-0 piece length
+  uint32_t K = 64;  // piece length for levels >= 1
+  static constexpr uint32_t SEG = 8;  // buckets per reduction segment
+};
+
+inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
+  MsmPlan p;
+  p.n = (uint32_t)n;
+  int best_c = 4;
+  double best = 1e300;
+  for (int c = 4; c <= 22; c++) {
+    int W = (254 + c - 1) / c;
+    // accumulation adds + ~6 group ops per bucket in the reduction (full adds cost ~1.4 mixed adds)
+    double cost = (double)W * (double)n + 8.0 * (double)W * (double)(1u << (c - 1));
+    if (cost < best) {
+      best = cost;
+      best_c = c;
+    }
+  }
+  if (force_c >= 4 && force_c <= 22) best_c = force_c;
+  p.c = best_c;
+  p.W = (254 + p.c - 1) / p.c;
+  p.Nb = 1u << (p.c - 1);
+  p.TB = p.W * p.Nb;
+  double avg = (double)n / (double)p.Nb;
+  uint32_t k0 = 32;
+  while (k0 < 2 * avg && k0 < 512) k0 <<= 1;
+  p.K0 = k0;
+  return p;
+}
+
+// ---- scalar recoding ------------------------------------------------------------------------
+// (r-1)/2 and r, 8 x u32 little-endian
+__device__ static const uint32_t kHalfR[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u,
+                                              0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+
+// s <- min(s, r - s); returns true when r - s was taken (the base must then be negated).
+ZK_DEV bool scalar_normalize(uint32_t (&s)[8]) {
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) (void)subb(kHalfR[i], s[i], bw);
+  if (!bw) return false;  // s <= (r-1)/2
+  uint32_t b2 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = subb(FrParams::P[i], s[i], b2);
+  return true;
+}
+
+ZK_DEV void scalar_shr(uint32_t (&s)[8], uint32_t c) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) s[i] = __builtin_amdgcn_alignbit(s[i + 1], s[i], c);
+  s[7] >>= c;
+}
+
+ZK_DEV void load_scalar(const void* scalars, uint32_t i, uint32_t (&s)[8]) {
+  const uint4* p = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
+  uint4 a = p[0], b = p[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+
+// ---- 1: count -------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void msm_count_kernel(const void* __restrict__ scalars, uint32_t n, uint32_t c,
+                                                        uint32_t W, uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ rank) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  bool valid = i < n;
+  uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) load_scalar(scalars, i, s);
+  (void)scalar_normalize(s);
+  const uint32_t Nb = 1u << (c - 1), mask = (1u << c) - 1u;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    uint32_t d = (s[0] & mask) + carry;
+    scalar_shr(s, c);
+    carry = d > Nb ? 1u : 0u;
+    uint32_t mag = carry ? (mask + 1u - d) : d;
+    bool emit = valid && mag != 0;
+    uint32_t key = w * Nb + mag - 1u;
+    bool is_hot = emit && mag == 1u;
+    unsigned long long hot = __ballot(is_hot);
+    if (emit) {
+      uint32_t r;
+      if (is_hot) {
+        int leader = __ffsll((long long)hot) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counts[key], (uint32_t)__popcll(hot));
+        base = __shfl(base, leader);
+        r = base + (uint32_t)__popcll(hot & ((1ull << lane) - 1ull));
+      } else {
+        r = atomicAdd(&counts[key], 1u);
+      }
+      rank[(size_t)w * n + i] = r;
+    }
+  }
+}
+
+// ---- 2: scan (u32, exclusive, n+1 outputs) ----------------------------------------------------
+// mode 0: v = in[i];  mode 1: v = ceil(in[i]/K);
+// mode 3: `in` is an offsets array with n+1 entries: x = in[i+1]-in[i]; v = x <= 1 ? 0 : ceil(x/K)
+ZK_DEV uint32_t scan_input(const uint32_t* __restrict__ in, uint32_t idx, uint32_t n, int mode, uint32_t K,
+                           uint32_t& raw) {
+  if (idx >= n) {
+    raw = 0;
+    return 0;
+  }
+  uint32_t x = in[idx];
+  if (mode == 3) x = in[idx + 1] - x;
+  raw = x;
+  if (mode == 0) return x;
+  if (mode == 3 && x <= 1) return 0;
+  return (x + K - 1) / K;
+}
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+ZK_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
+  // wave scan via shuffles, then 4 wave totals through LDS
+  uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanBlock / 64; k++) {
+    uint32_t t = lds[k];
+    if ((uint32_t)k < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + x - v;
+}
+
+static __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, int mode,
+                                                                 uint32_t K, uint32_t* __restrict__ block_sums,
+                                                                 uint32_t* __restrict__ max_out) {
+  __shared__ uint32_t lds[8];
+  uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t sum = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    uint32_t x;
+    sum += scan_input(in, base + k, n, mode, K, x);
+    mx = x > mx ? x : mx;
+  }
+  uint32_t total;
+  (void)block_exclusive_scan(sum, lds, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  if (max_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      uint32_t y = __shfl_xor(mx, o);
+      mx = y > mx ? y : mx;
+    }
+    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(max_out, mx);
+  }
+}
+
+// single block: exclusive scan of block_sums in place, total -> *total_out
+static __global__ __launch_bounds__(kScanBlock) void scan_spine_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks,
+                                                                uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t lds[8];
+  uint32_t running = 0;
+  for (uint32_t start = 0; start < nblocks; start += kScanBlock) {
+    uint32_t idx = start + threadIdx.x;
+    uint32_t v = idx < nblocks ? block_sums[idx] : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(v, lds, total);
+    if (idx < nblocks) block_sums[idx] = running + ex;
+    running += total;
+  }
+  if (threadIdx.x == 0) *total_out = running;
+}
+
+static __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t n, int mode,
+                                                                uint32_t K, const uint32_t* __restrict__ block_sums,
+                                                                const uint32_t* __restrict__ total,
+                                                                uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[8];
+  uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    uint32_t raw;
+    v[k] = scan_input(in, base + k, n, mode, K, raw);
+    sum += v[k];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(sum, lds, tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    uint32_t idx = base + k;
+    if (idx < n) out[idx] = ex;
+    ex += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// out[0..n] = exclusive scan of transform(in[0..n)); out[n] = total (also in *total_dev).
+inline void scan_u32(hipStream_t st, const uint32_t* in, uint32_t n, int mode, uint32_t K, uint32_t* out,
+                     uint32_t* block_sums, uint32_t* total_dev, uint32_t* max_dev) {
+  uint32_t nblocks = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, in, n, mode, K, block_sums, max_dev);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kScanBlock), 0, st, block_sums, nblocks, total_dev);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, in, n, mode, K, block_sums, total_dev,
+                     out);
+}
+
+// ---- 3: scatter -----------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void msm_scatter_kernel(const void* __restrict__ scalars, uint32_t n, uint32_t c,
+                                                          uint32_t W, const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ rank,
+                                                          uint32_t* __restrict__ sorted) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  load_scalar(scalars, i, s);
+  bool neg = scalar_normalize(s);
+  const uint32_t Nb = 1u << (c - 1), mask = (1u << c) - 1u;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    uint32_t d = (s[0] & mask) + carry;
+    scalar_shr(s, c);
+    carry = d > Nb ? 1u : 0u;
+    uint32_t mag = carry ? (mask + 1u - d) : d;
+    if (mag != 0) {
+      uint32_t key = w * Nb + mag - 1u;
+      bool sign = (carry != 0) != neg;
+      uint32_t pos = offsets[key] + rank[(size_t)w * n + i];
+      sorted[pos] = i | (sign ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// ---- 4: accumulate --------------------------------------------------------------------------
+// largest b in [0, nb) with po[b] <= t  (po has nb+1 entries, non-decreasing, po[nb] > t)
+ZK_DEV uint32_t find_bucket(const uint32_t* __restrict__ po, uint32_t nb, uint32_t t) {
+  uint32_t lo = 0, hi = nb;  // invariant: po[lo] <= t < po[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (po[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// level 0: items are sorted point indices; piece j of bucket b covers entries
+// [off0[b] + j*K0, min(off0[b] + cnt0[b], +K0)).
+template <class F>
+static __global__ __launch_bounds__(256) void msm_accum0_kernel(const void* __restrict__ bases,
+                                                         const uint32_t* __restrict__ sorted,
+                                                         const uint32_t* __restrict__ cnt0,
+                                                         const uint32_t* __restrict__ off0,
+                                                         const uint32_t* __restrict__ po1, uint32_t TB, uint32_t K0,
+                                                         void* __restrict__ buckets, void* __restrict__ P1) {
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  uint32_t total = po1[TB];
+  if (t >= total) return;
+  uint32_t b = find_bucket(po1, TB, t);
+  uint32_t j = t - po1[b];
+  uint32_t cnt = cnt0[b];
+  uint32_t start = off0[b] + j * K0;
+  uint32_t end = off0[b] + cnt;
+  if (end - start > K0) end = start + K0;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  uint32_t e = sorted[start];
+  Affine<F> p = load_affine<F>(bases, e & 0x7fffffffu);
+  for (uint32_t k = start; k < end; k++) {
+    uint32_t e_cur = e;
+    Affine<F> p_cur = p;
+    if (k + 1 < end) {  // prefetch the next base under this addition
+      e = sorted[k + 1];
+      p = load_affine<F>(bases, e & 0x7fffffffu);
+    }
+    xyzz_add_affine(acc, p_cur, (e_cur >> 31) != 0);
+  }
+  uint32_t pieces = (cnt + K0 - 1) / K0;
+  if (pieces == 1) store_xyzz(buckets, b, acc);
+  else store_xyzz(P1, t, acc);
+}
+
+// level l >= 1: items are XYZZ partial sums. Input items of bucket b: pin = pc_in[b] > 1 ? pc_in[b] : 0,
+// stored at Pin[po_in[b] ...]; output pieces enumerated by po_out.
+template <class F>
+static __global__ __launch_bounds__(256) void msm_accumN_kernel(const void* __restrict__ Pin,
+                                                         const uint32_t* __restrict__ po_in,
+                                                         const uint32_t* __restrict__ po_out, uint32_t TB, uint32_t K,
+                                                         void* __restrict__ buckets, void* __restrict__ Pout) {
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  uint32_t total = po_out[TB];
+  if (t >= total) return;
+  uint32_t b = find_bucket(po_out, TB, t);
+  uint32_t j = t - po_out[b];
+  uint32_t cnt = po_in[b + 1] - po_in[b];  // > 1 here, or this bucket would have no output piece
+  uint32_t start = po_in[b] + j * K;
+  uint32_t end = po_in[b] + cnt;
+  if (end - start > K) end = start + K;
+  XYZZ<F> acc = load_xyzz<F>(Pin, start);
+  for (uint32_t k = start + 1; k < end; k++) {
+    XYZZ<F> q = load_xyzz<F>(Pin, k);
+    xyzz_add(acc, q);
+  }
+  uint32_t pieces = po_out[b + 1] - po_out[b];
+  if (pieces == 1) store_xyzz(buckets, b, acc);
+  else store_xyzz(Pout, t, acc);
+}
+
+// ---- 5: bucket reduction ----------------------------------------------------------------------
+template <class F>
+__device__ __noinline__ void xyzz_add_ni(XYZZ<F>& a, const XYZZ<F>& b) {
+  xyzz_add(a, b);
+}
+template <class F>
+__device__ __noinline__ void xyzz_dbl_ni(XYZZ<F>& a) {
+  a = xyzz_dbl(a);
+}
+
+// thread g: segment of SEG buckets [g*SEG, +SEG) inside window g / (Nb/SEG).
+// X[g] = sum_j (j+1) * B[g*SEG+j]  +  (gw*SEG) * sum_j B[g*SEG+j],   gw = segment index in its window.
+template <class F>
+static __global__ __launch_bounds__(256) void msm_reduce_seg_kernel(const void* __restrict__ buckets, uint32_t TB,
+                                                             uint32_t Nb, void* __restrict__ X) {
+  constexpr uint32_t SEG = MsmPlan::SEG;
+  uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= TB / SEG) return;
+  uint32_t segs_per_window = Nb / SEG;
+  uint32_t gw = g % segs_per_window;
+  XYZZ<F> acc = XYZZ<F>::inf(), wt = XYZZ<F>::inf();
+  for (int j = (int)SEG - 1; j >= 0; j--) {
+    XYZZ<F> bkt = load_xyzz<F>(buckets, (size_t)g * SEG + j);
+    xyzz_add_ni(acc, bkt);
+    xyzz_add_ni(wt, acc);
+  }
+  // wt += (gw*SEG) * acc, MSB-first double-and-add
+  uint32_t k = gw * SEG;
+  if (k != 0 && !acc.is_inf()) {
+    XYZZ<F> r = acc;
+    int top = 31 - __builtin_clz(k);
+    for (int bit = top - 1; bit >= 0; bit--) {
+      xyzz_dbl_ni(r);
+      if ((k >> bit) & 1u) xyzz_add_ni(r, acc);
+    }
+    xyzz_add_ni(wt, r);
+  }
+  store_xyzz(X, g, wt);
+}
+
+// Y[w][blockIdx.x] = sum of X[w][blockIdx.x*256 .. +256) (S entries per window), LDS tree.
+template <class F>
+static __global__ __launch_bounds__(256) void msm_tree_sum_kernel(const void* __restrict__ X, uint32_t S, uint32_t S_out,
+                                                           void* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  uint32_t w = blockIdx.y;
+  uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  XYZZ<F> v = XYZZ<F>::inf();
+  if (idx < S) v = load_xyzz<F>(X, (size_t)w * S + idx);
+  store_xyzz(lds_raw, threadIdx.x, v);
+  __syncthreads();
+  for (uint32_t stride = 128; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      XYZZ<F> o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
+      xyzz_add_ni(v, o);
+      store_xyzz(lds_raw, threadIdx.x, v);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_xyzz(Y, (size_t)w * S_out + blockIdx.x, v);
+}
+
+// ---- host driver ------------------------------------------------------------------------------
+template <class F>
+struct MsmSizes {
+  static constexpr size_t kAffine = 2 * FieldBytes<F>::N;
+  static constexpr size_t kXyzz = 4 * FieldBytes<F>::N;
+};
+
+// bytes of workspace an MSM of n points needs (upper bound)
+template <class F>
+inline size_t msm_workspace_bytes(const MsmPlan& p) {
+  size_t T = (size_t)p.n * p.W;
+  size_t p1 = T / p.K0 + p.TB + 1;
+  size_t p2 = p1 / 2 + 1;
+  size_t segs = p.TB / MsmPlan::SEG;
+  size_t bytes = 0;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  bytes += al((size_t)p.TB * 4) * 2;        // counts, (spare)
+  bytes += al(((size_t)p.TB + 1) * 4) * 4;  // off0, po_a, po_b, po_c
+  bytes += al(T * 4) * 2;                   // rank, sorted
+  bytes += al(((size_t)p.TB / kScanTile + 2) * 4);
+  bytes += al(64);
+  bytes += al((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
+  bytes += al(p1 * MsmSizes<F>::kXyzz);            // P1
+  bytes += al(p2 * MsmSizes<F>::kXyzz);            // P2
+  bytes += al(segs * MsmSizes<F>::kXyzz);          // X
+  bytes += al((segs / 256 + p.W) * MsmSizes<F>::kXyzz) * 2;
+  return bytes + (1 << 16);
+}
+
+// Runs the device part of one MSM on lane.stream. d_bases / d_scalars are device pointers.
+// On return (stream synchronised) window_sums (host, W * XYZZ bytes, Montgomery) hold the per-window
+// sums sum_b b*B[w][b]; the caller combines them (host Horner). Returns the plan used.
+template <class F>
+inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
+                          int force_c = 0, float* accum_ms = nullptr) {
+  MsmPlan p = msm_make_plan(n, force_c);
+  hipStream_t st = lane.stream;
+  size_t need = msm_workspace_bytes<F>(p);
+  if (lane.ws.cap < need) {
+    ZK_HIP(hipStreamSynchronize(st));
+    lane.ws.reserve(need);
+  }
+  Arena& ws = lane.ws;
+  ws.reset();
+  const size_t T_max = (size_t)p.n * p.W;
+  uint32_t* counts = ws.take<uint32_t>(p.TB);
+  uint32_t* off0 = ws.take<uint32_t>(p.TB + 1);
+  uint32_t* po_a = ws.take<uint32_t>(p.TB + 1);
+  uint32_t* po_b = ws.take<uint32_t>(p.TB + 1);
+  uint32_t* rank = ws.take<uint32_t>(T_max);
+  uint32_t* sorted = ws.take<uint32_t>(T_max);
+  uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
+  uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
+  char* buckets = ws.take<char>((size_t)p.TB * MsmSizes<F>::kXyzz);
+  size_t p1_cap = T_max / p.K0 + p.TB + 1;
+  size_t p2_cap = p1_cap / 2 + 1;
+  char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
+  char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
+  const uint32_t segs = p.TB / MsmPlan::SEG;
+  const uint32_t S0 = p.Nb / MsmPlan::SEG;
+  char* X = ws.take<char>((size_t)segs * MsmSizes<F>::kXyzz);
+  const uint32_t S1 = (S0 + 255) / 256;
+  char* Y1 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
+  char* Y2 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
+
+  ZK_HIP(hipMemsetAsync(counts, 0, (size_t)p.TB * 4, st));
+  ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
+  ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
+  const uint32_t nblk = (p.n + 255) / 256;
+  if (p.n) {
+    hipLaunchKernelGGL(msm_count_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, counts, rank);
+  }
+  scan_u32(st, counts, p.TB, 0, 0, off0, block_sums, misc + 0, misc + 1);
+  scan_u32(st, counts, p.TB, 1, p.K0, po_a, block_sums, misc + 2, nullptr);
+  if (p.n) {
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, off0, rank, sorted);
+  }
+  uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
+  ZK_HIP(hipMemcpyAsync(hb, misc, 16, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  const uint32_t max_count = hb[1];
+  const uint32_t total1 = hb[2];
+  if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
+  if (total1) {
+    hipLaunchKernelGGL((msm_accum0_kernel<F>), dim3((total1 + 255) / 256), dim3(256), 0, st, d_bases, sorted, counts,
+                       off0, po_a, p.TB, p.K0, (void*)buckets, (void*)P1);
+  }
+  if (accum_ms) ZK_HIP(hipEventRecord(lane.ev1, st));
+  // further levels while some bucket still has more than one partial sum
+  uint64_t max_items = ((uint64_t)max_count + p.K0 - 1) / p.K0;  // max items per bucket entering level 1
+  uint64_t total_in = total1;                                      // upper bound of items entering the level
+  uint32_t* po_in = po_a;
+  uint32_t* po_out = po_b;
+  char* Pin = P1;
+  char* Pout = P2;
+  size_t cap_out = p2_cap, cap_in = p1_cap;
+  while (max_items > 1) {
+    uint64_t bound = total_in / 2 + 1;  // every unfinished bucket holds >= 2 items and emits <= items/2 + 1 pieces
+    if (bound > cap_out) throw HipError("msm: level buffer too small");
+    scan_u32(st, po_in, p.TB, 3, p.K, po_out, block_sums, misc + 3, nullptr);
+    hipLaunchKernelGGL((msm_accumN_kernel<F>), dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, st, (const void*)Pin,
+                       po_in, po_out, p.TB, p.K, (void*)buckets, (void*)Pout);
+    max_items = (max_items + p.K - 1) / p.K;
+    total_in = bound;
+    std::swap(po_in, po_out);
+    std::swap(Pin, Pout);
+    std::swap(cap_in, cap_out);
+  }
+  // bucket reduction
+  hipLaunchKernelGGL((msm_reduce_seg_kernel<F>), dim3((segs + 255) / 256), dim3(256), 0, st, (const void*)buckets, p.TB,
+                     p.Nb, (void*)X);
+  const char* cur = X;
+  uint32_t S = S0;
+  char* ybuf[2] = {Y1, Y2};
+  int yi = 0;
+  while (true) {
+    uint32_t S_out = (S + 255) / 256;
+    // Y1 holds up to S1*W entries, Y2 up to W*ceil(S1/256) <= Y1's size as well when S1 > 256: size both by S1*W
+    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, p.W), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+                       (const void*)cur, S, S_out, (void*)ybuf[yi]);
+    cur = ybuf[yi];
+    yi ^= 1;
+    S = S_out;
+    if (S == 1) break;
+  }
+  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)p.W * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+  memcpy(window_sums_host, lane.pinned, (size_t)p.W * MsmSizes<F>::kXyzz);
+  if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));
+  return p;
+}
+
+}  // namespace zkpoa

@@ -1,0 +1,8 @@
+// G2 instantiation of the Pippenger MSM (zkey section 7: B2 query).
+#include "msm_run.hip.h"
+
+namespace zkpoa {
+void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out) {
+  msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out);
+}
+}  // namespace zkpoa

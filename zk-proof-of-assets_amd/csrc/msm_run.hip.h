@@ -1,0 +1,24 @@
+// Host driver shared by msm_g1.hip / msm_g2.hip: device MSM + host window combination.
+#pragma once
+#include "msm.hip.h"
+#include "zkpoa_internal.hpp"
+
+namespace zkpoa {
+template <class F, class HF>
+void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out) {
+  Lane& lane = ctx->dev.lanes[lane_id];
+  std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
+  float acc_ms = 0;
+  ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
+  MsmPlan p = msm_device<F>(lane, d_bases, d_scalars, (size_t)n, wsums.data(), ctx->opt_msm_c, &acc_ms);
+  ZK_HIP(hipEventRecord(ctx->ev_b[lane_id], lane.stream));
+  ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));
+  float tot = 0;
+  ZK_HIP(hipEventElapsedTime(&tot, ctx->ev_a[lane_id], ctx->ev_b[lane_id]));
+  ctx->ms[0] = tot;
+  ctx->ms[1] = acc_ms;
+  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.W, p.c);
+  h_affine_to_bytes<HF>(h_to_affine(r), out);
+}
+
+}  // namespace zkpoa

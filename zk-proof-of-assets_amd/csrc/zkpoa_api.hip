@@ -1,0 +1,161 @@
+// C-ABI glue of libzkpoa_prover.so (see include/zkpoa_prover.h): context, options, timings,
+// MSM entry points, host-only group helpers. Kernels live in the per-group translation units.
+#include "zkpoa_internal.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+using namespace zkpoa;
+
+namespace zkpoa {
+void set_err(char* buf, unsigned long cap, const std::string& msg) {
+  if (!buf || cap == 0) return;
+  size_t k = msg.size() < cap - 1 ? msg.size() : cap - 1;
+  memcpy(buf, msg.data(), k);
+  buf[k] = 0;
+}
+}  // namespace zkpoa
+
+// ---- context -----------------------------------------------------------------------------------
+extern "C" int zkpoa_context_create(int device, zkpoa_context** out, char* error_msg, unsigned long error_msg_maxsize) {
+  if (!out) return PROVER_ERROR;
+  *out = nullptr;
+  zkpoa_context* c = new zkpoa_context();
+  try {
+    c->dev.init(device);
+    for (int i = 0; i < DeviceCtx::kLanes; i++) {
+      ZK_HIP(hipEventCreate(&c->ev_a[i]));
+      ZK_HIP(hipEventCreate(&c->ev_b[i]));
+    }
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    delete c;
+    return PROVER_ERROR;
+  }
+  *out = c;
+  return PROVER_OK;
+}
+
+extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->dev.device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < DeviceCtx::kLanes; i++) {
+    if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
+    if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
+  }
+  ctx->dev.destroy();
+  delete ctx;
+}
+
+extern "C" const char* zkpoa_last_error(const zkpoa_context* ctx) {
+  return ctx ? ctx->last_error.c_str() : "null context";
+}
+
+extern "C" float zkpoa_last_ms(const zkpoa_context* ctx, int id) {
+  if (!ctx || id < 0 || id >= 8) return -1.f;
+  return ctx->ms[id];
+}
+
+extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value) {
+  if (!ctx || !key) return PROVER_ERROR;
+  if (!strcmp(key, "msm_c")) {
+    ctx->opt_msm_c = (int)value;
+    return PROVER_OK;
+  }
+  ctx->last_error = std::string("unknown option ") + key;
+  return PROVER_ERROR;
+}
+
+// ---- MSM ---------------------------------------------------------------------------------------
+static void check_n(uint64_t n) {
+  if (n > (1ull << 27)) throw HipError("msm: n too large (max 2^27 points per call)");
+}
+
+extern "C" int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n,
+                                   uint8_t out[64]) {
+  ZK_API_BEGIN(ctx)
+  check_n(n);
+  msm_run_g1(ctx, 0, d_bases, d_scalars, n, out);
+  ZK_API_END(ctx)
+}
+extern "C" int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n,
+                                   uint8_t out[128]) {
+  ZK_API_BEGIN(ctx)
+  check_n(n);
+  msm_run_g2(ctx, 0, d_bases, d_scalars, n, out);
+  ZK_API_END(ctx)
+}
+extern "C" int zkpoa_msm_g1(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[64]) {
+  ZK_API_BEGIN(ctx)
+  check_n(n);
+  DevBuf db(n * 64), ds(n * 32);
+  ZK_HIP(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
+  ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  msm_run_g1(ctx, 0, db.p, ds.p, n, out);
+  ZK_API_END(ctx)
+}
+extern "C" int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[128]) {
+  ZK_API_BEGIN(ctx)
+  check_n(n);
+  DevBuf db(n * 128), ds(n * 32);
+  ZK_HIP(hipMemcpy(db.p, bases, n * 128, hipMemcpyHostToDevice));
+  ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  msm_run_g2(ctx, 0, db.p, ds.p, n, out);
+  ZK_API_END(ctx)
+}
+
+// ---- synthetic bases / element-wise hooks --------------------------------------------------------
+extern "C" int zkpoa_gen_bases_g1_device(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32],
+                                         uint64_t i0, uint64_t n, void* d_out) {
+  ZK_API_BEGIN(ctx)
+  gen_bases_g1(ctx, a_le, b_le, i0, n, d_out);
+  ZK_API_END(ctx)
+}
+extern "C" int zkpoa_gen_bases_g2_device(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32],
+                                         uint64_t i0, uint64_t n, void* d_out) {
+  ZK_API_BEGIN(ctx)
+  gen_bases_g2(ctx, a_le, b_le, i0, n, d_out);
+  ZK_API_END(ctx)
+}
+extern "C" int zkpoa_group_add(zkpoa_context* ctx, int group, const void* a, const void* b, void* out, uint64_t n) {
+  ZK_API_BEGIN(ctx)
+  if (n == 0) return PROVER_OK;
+  if (group == 1) group_add_run_g1(ctx, a, b, out, n);
+  else if (group == 2) group_add_run_g2(ctx, a, b, out, n);
+  else throw HipError("group_add: group must be 1 or 2");
+  ZK_API_END(ctx)
+}
+
+// ---- host-only group helpers ---------------------------------------------------------------------
+template <class HF>
+static int group_sum(const void* points, uint64_t count, uint8_t* out) {
+  constexpr size_t A = 2 * HostBytes<HF>::N;
+  XYZZ<HF> acc = XYZZ<HF>::inf();
+  for (uint64_t i = 0; i < count; i++) {
+    Affine<HF> p = h_affine_from_bytes<HF>(reinterpret_cast<const char*>(points) + i * A);
+    xyzz_add_affine(acc, p, false);
+  }
+  h_affine_to_bytes<HF>(h_to_affine(acc), out);
+  return PROVER_OK;
+}
+extern "C" int zkpoa_g1_sum(const void* points, uint64_t count, uint8_t out[64]) {
+  return group_sum<HFq>(points, count, out);
+}
+extern "C" int zkpoa_g2_sum(const void* points, uint64_t count, uint8_t out[128]) {
+  return group_sum<HFq2>(points, count, out);
+}
+template <class HF>
+static int group_mul(const uint8_t* point, const uint8_t* scalar_le, uint8_t* out) {
+  uint64_t k[4];
+  memcpy(k, scalar_le, 32);
+  Affine<HF> p = h_affine_from_bytes<HF>(point);
+  h_affine_to_bytes<HF>(h_to_affine(h_mul(XYZZ<HF>::from_affine(p), k)), out);
+  return PROVER_OK;
+}
+extern "C" int zkpoa_g1_mul(const uint8_t point[64], const uint8_t scalar_le[32], uint8_t out[64]) {
+  return group_mul<HFq>(point, scalar_le, out);
+}
+extern "C" int zkpoa_g2_mul(const uint8_t point[128], const uint8_t scalar_le[32], uint8_t out[128]) {
+  return group_mul<HFq2>(point, scalar_le, out);
+}

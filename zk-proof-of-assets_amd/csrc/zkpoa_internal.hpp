@@ -1,0 +1,53 @@
+// Internal C++ view of the opaque handles declared in include/zkpoa_prover.h.
+#pragma once
+#include "../../include/zkpoa_prover.h"
+#include "device_ctx.hpp"
+#include "host_curve.hpp"
+
+#include <string>
+#include <vector>
+
+struct zkpoa_context {
+  zkpoa::DeviceCtx dev;
+  std::string last_error;
+  float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int opt_msm_c = 0;
+  hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
+  hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
+};
+
+namespace zkpoa {
+void set_err(char* buf, unsigned long cap, const std::string& msg);
+
+struct DevBuf {  // RAII device allocation for the host-buffer entry points
+  void* p = nullptr;
+  explicit DevBuf(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 1)); }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+
+// per-group entry points, each compiled in its own translation unit (msm_g1.hip, msm_g2.hip, ...)
+void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out);
+void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out);
+void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
+void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
+void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
+void gen_bases_g2(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
+}  // namespace zkpoa
+
+#define ZK_API_BEGIN(ctx)  \
+  if (!(ctx)) return PROVER_ERROR; \
+  try {                    \
+    ZK_HIP(hipSetDevice((ctx)->dev.device));
+#define ZK_API_END(ctx)                 \
+  }                                     \
+  catch (const std::exception& e) {     \
+    (ctx)->last_error = e.what();       \
+    return PROVER_ERROR;                \
+  }                                     \
+  return PROVER_OK;
+
