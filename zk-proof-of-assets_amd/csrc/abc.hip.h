@@ -1,0 +1,99 @@
+// buildABC / joinABC on the device.
+//
+// Replaces snarkjs groth16_prove.js::buildABC1 + joinABC (SURVEY.md 3.2 steps 2 and 4, 8a rows
+// a5/a7) and the coefficient loop of rapidsnark's groth16.cpp:
+//   out[m][c] += coef (x) w[s]      for every record (m, c, s, coef*R^2) of zkey section 4
+//   C[c] = A[c] (x) B[c]
+//   P[i] = fromMontgomery(A'[i] (x) B'[i] - C'[i])
+// (x) = Montgomery product; witness values are standard form, so the products come out in
+// Montgomery form of coef*w.
+//
+// The 44-byte records arrive in file order. Field elements have no atomic add, so the records
+// are bucketed by output row once per proving key (counting sort on key = 2*c + m, done at
+// zkey load: it depends on the key only) into CSR arrays; per proof one thread per constraint
+// walks its two rows. HBM-bound: 36 B (value + signal index) + 32 B gathered witness per record.
+#pragma once
+#include "bn254_field.hip.h"
+#include "device_ctx.hpp"
+
+namespace zkpoa {
+
+struct CoefRec {  // 44 bytes, 4-byte aligned, as stored in zkey section 4 after the u32 count
+  uint32_t m, c, s;
+  uint32_t val[8];
+};
+static_assert(sizeof(CoefRec) == 44, "coef record");
+
+// pass 1: validate + histogram rows, remember the rank inside the row. err[0] != 0 on bad records.
+static __global__ __launch_bounds__(256) void abc_count_kernel(const CoefRec* __restrict__ recs, uint64_t ncoef,
+                                                               uint32_t domain, uint32_t nvars,
+                                                               uint32_t* __restrict__ row_cnt,
+                                                               uint32_t* __restrict__ rank, uint32_t* __restrict__ err) {
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= ncoef) return;
+  uint32_t m = recs[i].m, c = recs[i].c, s = recs[i].s;
+  if (m > 1u || c >= domain || s >= nvars) {
+    atomicOr(err, 1u);
+    rank[i] = 0;
+    return;
+  }
+  rank[i] = atomicAdd(&row_cnt[2u * c + m], 1u);
+}
+
+// pass 2: scatter into CSR order
+static __global__ __launch_bounds__(256) void abc_scatter_kernel(const CoefRec* __restrict__ recs, uint64_t ncoef,
+                                                                 const uint32_t* __restrict__ row_ptr,
+                                                                 const uint32_t* __restrict__ rank,
+                                                                 uint32_t* __restrict__ sig, void* __restrict__ vals) {
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= ncoef) return;
+  uint32_t m = recs[i].m, c = recs[i].c;
+  if (m > 1u) return;
+  uint32_t pos = row_ptr[2u * c + m] + rank[i];
+  sig[pos] = recs[i].s;
+  Fr v;
+#pragma unroll
+  for (int k = 0; k < 8; k++) v.l[k] = recs[i].val[k];
+  store_field(reinterpret_cast<char*>(vals) + 32 * (size_t)pos, v);
+}
+
+ZK_DEV Fr abc_row_sum(const uint32_t* __restrict__ row_ptr, uint32_t row, const uint32_t* __restrict__ sig,
+                      const void* __restrict__ vals, const void* __restrict__ witness) {
+  Fr acc = Fr::zero();
+  uint32_t b = row_ptr[row], e = row_ptr[row + 1];
+  for (uint32_t k = b; k < e; k++) {
+    Fr v = load_field<Fr>(reinterpret_cast<const char*>(vals) + 32 * (size_t)k);
+    Fr w = load_field<Fr>(reinterpret_cast<const char*>(witness) + 32 * (size_t)sig[k]);
+    acc = acc + v * w;
+  }
+  return acc;
+}
+
+// one thread per constraint c: A_T[c], B_T[c], C_T[c] = A (x) B
+static __global__ __launch_bounds__(256) void abc_rows_kernel(const uint32_t* __restrict__ row_ptr,
+                                                              const uint32_t* __restrict__ sig,
+                                                              const void* __restrict__ vals,
+                                                              const void* __restrict__ witness, uint32_t domain,
+                                                              void* __restrict__ A, void* __restrict__ B,
+                                                              void* __restrict__ C) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= domain) return;
+  Fr a = abc_row_sum(row_ptr, 2u * c, sig, vals, witness);
+  Fr b = abc_row_sum(row_ptr, 2u * c + 1u, sig, vals, witness);
+  store_field(reinterpret_cast<char*>(A) + 32 * (size_t)c, a);
+  store_field(reinterpret_cast<char*>(B) + 32 * (size_t)c, b);
+  store_field(reinterpret_cast<char*>(C) + 32 * (size_t)c, a * b);
+}
+
+// P[i] = fromMontgomery(A[i] (x) B[i] - C[i]); written over A
+static __global__ __launch_bounds__(256) void abc_join_kernel(void* __restrict__ A, const void* __restrict__ B,
+                                                              const void* __restrict__ C, uint32_t domain) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= domain) return;
+  Fr a = load_field<Fr>(reinterpret_cast<const char*>(A) + 32 * (size_t)i);
+  Fr b = load_field<Fr>(reinterpret_cast<const char*>(B) + 32 * (size_t)i);
+  Fr c = load_field<Fr>(reinterpret_cast<const char*>(C) + 32 * (size_t)i);
+  store_field(reinterpret_cast<char*>(A) + 32 * (size_t)i, (a * b - c).from_mont());
+}
+
+}  // namespace zkpoa

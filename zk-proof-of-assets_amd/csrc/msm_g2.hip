@@ -2,7 +2,8 @@
 #include "msm_run.hip.h"
 
 namespace zkpoa {
-void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out) {
-  msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out);
+void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
+                float* ms2) {
+  msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out, ms2);
 }
 }  // namespace zkpoa

@@ -5,7 +5,9 @@
 
 namespace zkpoa {
 template <class F, class HF>
-void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out) {
+// ms2 (optional): [0] = device time of the whole MSM, [1] = its level-0 bucket-accumulation kernel
+void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
+             float* ms2) {
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
   float acc_ms = 0;
@@ -15,8 +17,10 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));
   float tot = 0;
   ZK_HIP(hipEventElapsedTime(&tot, ctx->ev_a[lane_id], ctx->ev_b[lane_id]));
-  ctx->ms[0] = tot;
-  ctx->ms[1] = acc_ms;
+  if (ms2) {
+    ms2[0] = tot;
+    ms2[1] = acc_ms;
+  }
   XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.W, p.c);
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }

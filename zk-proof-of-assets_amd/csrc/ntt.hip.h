@@ -1,0 +1,325 @@
+// Radix-2 number-theoretic transform over the BN254 scalar field Fr for gfx950, LDS-staged.
+//
+// Replaces Fr.fft / Fr.ifft / Fr.batchApplyKey of ffjavascript as used by snarkjs
+// groth16_prove.js and rapidsnark's fft.hpp: six size-n
+// transforms per proof, w = w[log2 n] (5^((r-1)/2^28) squared down), elements in Montgomery form.
+//
+// Structure: the log2(n) butterfly stages are cut into passes of B <= 11 consecutive stages.
+// One workgroup stages a tile of 2^B rows x T columns (2048 elements, 64 KiB) in LDS, runs the
+// B stages there with one barrier per stage, and writes the tile back: every pass reads and
+// writes each element once (HBM-bound part), all butterflies run out of LDS.
+//   * DIF (Gentleman-Sande) passes go from the top stage down: natural order in, bit-reversed out.
+//   * DIT (Cooley-Tukey) passes go from stage 0 up: bit-reversed in, natural order out.
+// Between passes the four-step twiddle W_n^((n/N') * ka * rev_B(m)) is applied on the way out
+// (DIF) or in (DIT), looked up as Hi[e >> L] * Lo[e & (2^L - 1)] from two small tables, so inside
+// a pass every butterfly twiddle is a plain 2^B-th root from a 2^(B-1)-entry table.
+// The prover chain ifft -> coset shift -> fft is DIF(w^-1) -> pointwise -> DIT(w) and needs no
+// bit-reversal permutation at all; the natural-order API adds one in-place permutation kernel.
+#pragma once
+#include "bn254_field.hip.h"
+#include "device_ctx.hpp"
+#include "host_field.hpp"
+
+#include <map>
+#include <vector>
+
+namespace zkpoa {
+
+constexpr uint32_t kNttTileLog = 11;  // 2048 elements = 64 KiB of LDS per workgroup
+constexpr uint32_t kNttStridedB = 8;  // rows per tile in strided passes (x 8 columns)
+
+// T[i] = scale * base^(i * step) for i < count  (all Montgomery)
+static __global__ __launch_bounds__(256) void fr_pow_table_kernel(Fr base, Fr scale, uint32_t count, void* out) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  Fr acc = scale, b = base;
+  uint32_t e = i;
+  while (e) {
+    if (e & 1u) acc = acc * b;
+    b = b.sqr();
+    e >>= 1;
+  }
+  store_field(reinterpret_cast<char*>(out) + 32 * (size_t)i, acc);
+}
+
+// W^e from the two-level table: e = eh * 2^L + el
+ZK_DEV Fr tw_lookup(const void* __restrict__ hi, const void* __restrict__ lo, uint32_t L, uint32_t e) {
+  Fr a = load_field<Fr>(reinterpret_cast<const char*>(hi) + 32 * (size_t)(e >> L));
+  Fr b = load_field<Fr>(reinterpret_cast<const char*>(lo) + 32 * (size_t)(e & ((1u << L) - 1u)));
+  return a * b;
+}
+
+ZK_DEV Fr lds_load(const uint4* lds, uint32_t idx) {
+  uint4 a = lds[2 * idx], b = lds[2 * idx + 1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+ZK_DEV void lds_store(uint4* lds, uint32_t idx, const Fr& v) {
+  lds[2 * idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  lds[2 * idx + 1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// One pass over stages [s_lo, s_lo + B). Tile: 2^B rows (stride 2^s_lo elements) x 2^logT columns
+// (consecutive elements); requires logT <= s_lo. grid.x = n / 2^(B+logT).
+template <bool DIF>
+static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__ data, uint32_t k, uint32_t s_lo,
+                                                              uint32_t B, uint32_t logT,
+                                                              const void* __restrict__ small_tw,
+                                                              const void* __restrict__ tw_hi,
+                                                              const void* __restrict__ tw_lo, uint32_t L) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const uint32_t T = 1u << logT, tile = 1u << (B + logT), tid = threadIdx.x;
+  const uint32_t cg_count = (1u << s_lo) >> logT;
+  const uint32_t cg = blockIdx.x % cg_count;
+  const uint64_t U = blockIdx.x / cg_count;
+  const uint64_t base = (U << (s_lo + B)) + (uint64_t)cg * T;
+  const uint32_t shift = k - (s_lo + B);  // log2(n / N')
+  char* d = reinterpret_cast<char*>(data);
+
+  for (uint32_t e = tid; e < tile; e += 256u) {
+    uint32_t c = e & (T - 1u), m = e >> logT;
+    uint64_t p = base + ((uint64_t)m << s_lo) + c;
+    Fr v = load_field<Fr>(d + 32 * p);
+    if (!DIF && s_lo > 0) {
+      uint32_t r = __brev(m) >> (32u - B);
+      uint32_t ex = ((cg * T + c) * r) << shift;
+      v = v * tw_lookup(tw_hi, tw_lo, L, ex);
+    }
+    lds_store(lds, e, v);
+  }
+  __syncthreads();
+
+  for (uint32_t it = 0; it < B; it++) {
+    const uint32_t sl = DIF ? (B - 1u - it) : it;
+    const uint32_t half = 1u << sl;
+    for (uint32_t b = tid; b < (tile >> 1); b += 256u) {
+      uint32_t c = b & (T - 1u), mb = b >> logT;
+      uint32_t j = mb & (half - 1u);
+      uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
+      uint32_t i0 = (m0 << logT) + c, i1 = i0 + (half << logT);
+      Fr tw = load_field<Fr>(reinterpret_cast<const char*>(small_tw) + 32 * (size_t)(j << (B - 1u - sl)));
+      Fr u = lds_load(lds, i0), v = lds_load(lds, i1);
+      if (DIF) {
+        lds_store(lds, i0, u + v);
+        lds_store(lds, i1, (u - v) * tw);
+      } else {
+        v = v * tw;
+        lds_store(lds, i0, u + v);
+        lds_store(lds, i1, u - v);
+      }
+    }
+    __syncthreads();
+  }
+
+  for (uint32_t e = tid; e < tile; e += 256u) {
+    uint32_t c = e & (T - 1u), m = e >> logT;
+    uint64_t p = base + ((uint64_t)m << s_lo) + c;
+    Fr v = lds_load(lds, e);
+    if (DIF && s_lo > 0) {
+      uint32_t r = __brev(m) >> (32u - B);
+      uint32_t ex = ((cg * T + c) * r) << shift;
+      v = v * tw_lookup(tw_hi, tw_lo, L, ex);
+    }
+    store_field(d + 32 * p, v);
+  }
+}
+
+// in-place bit-reversal permutation of n = 2^k elements
+static __global__ __launch_bounds__(256) void fr_bitrev_kernel(void* data, uint32_t k) {
+  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (p >> k) return;
+  uint64_t r = (uint64_t)(__brev((uint32_t)p) >> (32u - k));
+  if (k == 0 || p >= r) return;
+  char* d = reinterpret_cast<char*>(data);
+  Fr a = load_field<Fr>(d + 32 * p), b = load_field<Fr>(d + 32 * r);
+  store_field(d + 32 * p, b);
+  store_field(d + 32 * r, a);
+}
+
+// data[p] *= Hi[j >> L] * Lo[j & mask], j = bitrev_k(p) if BITREV else p
+// (batchApplyKey(first, inc) with first folded into Lo; also the 1/n of the inverse transform)
+template <bool BITREV>
+static __global__ __launch_bounds__(256) void fr_scale_pow_kernel(void* data, uint32_t k, const void* __restrict__ hi,
+                                                                  const void* __restrict__ lo, uint32_t L) {
+  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (p >> k) return;
+  uint32_t j = BITREV ? (k ? (__brev((uint32_t)p) >> (32u - k)) : 0u) : (uint32_t)p;
+  char* d = reinterpret_cast<char*>(data) + 32 * p;
+  Fr v = load_field<Fr>(d);
+  store_field(d, v * tw_lookup(hi, lo, L, j));
+}
+
+// data[p] *= c
+static __global__ __launch_bounds__(256) void fr_scale_const_kernel(void* data, uint64_t n, Fr c) {
+  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (p >= n) return;
+  char* d = reinterpret_cast<char*>(data) + 32 * p;
+  store_field(d, load_field<Fr>(d) * c);
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct NttPassDesc {
+  uint32_t s_lo, B, logT;
+};
+
+// passes in DIT order (stage 0 upwards); DIF runs them in reverse
+inline std::vector<NttPassDesc> ntt_plan(uint32_t k) {
+  std::vector<NttPassDesc> v;
+  if (k == 0) return v;
+  uint32_t b0 = k < kNttTileLog ? k : kNttTileLog;
+  v.push_back({0, b0, 0});
+  uint32_t rest = k - b0;
+  if (rest) {
+    uint32_t npass = (rest + kNttStridedB - 1) / kNttStridedB;
+    uint32_t s = b0;
+    for (uint32_t i = 0; i < npass; i++) {
+      uint32_t b = rest / npass + (i < rest % npass ? 1 : 0);
+      v.push_back({s, b, kNttTileLog - kNttStridedB});
+      s += b;
+    }
+  }
+  return v;
+}
+
+inline HFr hfr_root_of_unity(uint32_t k) {  // w[k], Montgomery
+  // w[28] = 5^((r-1)/2^28)
+  static const uint64_t e28[4] = {0x9b9709143e1f593full, 0x181585d2833e8487ull, 0x131a029b85045b68ull,
+                                  0x000000030644e72eull};
+  HFr w = HFr::from_u64(5).pow(e28);
+  for (uint32_t i = 28; i > k; i--) w = w.sqr();
+  return w;
+}
+
+struct NttTables {  // device tables for one (k, direction)
+  uint32_t k = 0, L = 0;
+  void* hi = nullptr;                 // W^(i * 2^L), i < 2^(k-L)
+  void* lo = nullptr;                 // W^i, i < 2^L
+  std::map<uint32_t, void*> small;    // B -> W_{2^B}^t, t < 2^(B-1)
+};
+
+inline Fr to_dev(const HFr& h) {
+  Fr f;
+  memcpy(&f, &h, 32);
+  return f;
+}
+
+inline void build_pow_table(hipStream_t st, const HFr& base, const HFr& scale, uint32_t count, void* out) {
+  hipLaunchKernelGGL(fr_pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, st, to_dev(base), to_dev(scale),
+                     count, out);
+}
+
+struct NttEngine {
+  std::map<uint64_t, NttTables> cache;  // key = k*2 + inverse
+  std::map<uint64_t, std::pair<void*, void*>> coset_cache;  // k -> (hi, lo) of inc^j / n
+
+  static HFr hpow2(HFr x, uint32_t times) {
+    for (uint32_t i = 0; i < times; i++) x = x.sqr();
+    return x;
+  }
+
+  const NttTables& tables(hipStream_t st, uint32_t k, bool inverse) {
+    uint64_t key = (uint64_t)k * 2 + (inverse ? 1 : 0);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    NttTables t;
+    t.k = k;
+    t.L = (k + 1) / 2;
+    HFr w = hfr_root_of_unity(k);
+    if (inverse) w = w.inv();
+    uint32_t nlo = 1u << t.L, nhi = 1u << (k - t.L);
+    ZK_HIP(hipMalloc(&t.hi, (size_t)nhi * 32));
+    ZK_HIP(hipMalloc(&t.lo, (size_t)nlo * 32));
+    build_pow_table(st, hpow2(w, t.L), HFr::one(), nhi, t.hi);
+    build_pow_table(st, w, HFr::one(), nlo, t.lo);
+    for (const auto& ps : ntt_plan(k)) {
+      if (t.small.count(ps.B)) continue;
+      void* p = nullptr;
+      uint32_t cnt = ps.B ? (1u << (ps.B - 1)) : 1u;
+      ZK_HIP(hipMalloc(&p, (size_t)cnt * 32));
+      build_pow_table(st, hpow2(w, k - ps.B), HFr::one(), cnt, p);  // W_{2^B} = W^(2^(k-B))
+      t.small[ps.B] = p;
+    }
+    return cache.emplace(key, t).first->second;
+  }
+
+  // tables for p -> (inc^j) * scale with j < 2^k
+  std::pair<void*, void*> pow_tables(hipStream_t st, uint32_t k, const HFr& g, const HFr& scale, uint64_t cache_key) {
+    auto it = coset_cache.find(cache_key);
+    if (it != coset_cache.end()) return it->second;
+    uint32_t L = (k + 1) / 2;
+    void *hi = nullptr, *lo = nullptr;
+    ZK_HIP(hipMalloc(&hi, (size_t)(1u << (k - L)) * 32));
+    ZK_HIP(hipMalloc(&lo, (size_t)(1u << L) * 32));
+    build_pow_table(st, hpow2(g, L), HFr::one(), 1u << (k - L), hi);
+    build_pow_table(st, g, scale, 1u << L, lo);
+    return coset_cache.emplace(cache_key, std::make_pair(hi, lo)).first->second;
+  }
+
+  template <bool DIF>
+  void run_passes(hipStream_t st, void* d_data, uint32_t k, bool inverse) {
+    if (k == 0) return;
+    const NttTables& t = tables(st, k, inverse);
+    auto plan = ntt_plan(k);
+    for (size_t idx = 0; idx < plan.size(); idx++) {
+      const NttPassDesc& ps = DIF ? plan[plan.size() - 1 - idx] : plan[idx];
+      uint32_t tile_log = ps.B + ps.logT;
+      uint32_t grid = 1u << (k - tile_log);
+      size_t lds_bytes = (size_t)32 << tile_log;
+      hipLaunchKernelGGL((ntt_pass_kernel<DIF>), dim3(grid), dim3(256), lds_bytes, st, d_data, k, ps.s_lo, ps.B,
+                         ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi, (const void*)t.lo, t.L);
+    }
+  }
+
+  // natural -> bit-reversed, root w (or w^-1)
+  void dif(hipStream_t st, void* d, uint32_t k, bool inverse) { run_passes<true>(st, d, k, inverse); }
+  // bit-reversed -> natural
+  void dit(hipStream_t st, void* d, uint32_t k, bool inverse) { run_passes<false>(st, d, k, inverse); }
+
+  void bitrev(hipStream_t st, void* d, uint32_t k) {
+    uint64_t n = 1ull << k;
+    hipLaunchKernelGGL(fr_bitrev_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, k);
+  }
+
+  // Fr.fft / Fr.ifft semantics: natural order in and out
+  void transform_natural(hipStream_t st, void* d, uint32_t k, bool inverse) {
+    dif(st, d, k, inverse);
+    bitrev(st, d, k);
+    if (inverse) {
+      uint64_t n = 1ull << k;
+      HFr ninv = HFr::from_u64(n).inv();
+      hipLaunchKernelGGL(fr_scale_const_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, n,
+                         to_dev(ninv));
+    }
+  }
+
+  // evaluations on the domain -> evaluations on the odd coset (ifft, batchApplyKey(1, inc), fft)
+  void to_odd_coset(hipStream_t st, void* d, uint32_t k) {
+    if (k == 0) return;  // n = 1: constant polynomial
+    uint64_t n = 1ull << k;
+    HFr inc = (k == 28) ? HFr::from_u64(25) : hfr_root_of_unity(k + 1);
+    HFr ninv = HFr::from_u64(n).inv();
+    auto tb = pow_tables(st, k, inc, ninv, k);
+    dif(st, d, k, true);
+    hipLaunchKernelGGL((fr_scale_pow_kernel<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, k,
+                       (const void*)tb.first, (const void*)tb.second, (k + 1) / 2);
+    dit(st, d, k, false);
+  }
+
+  void release() {
+    for (auto& kv : cache) {
+      (void)hipFree(kv.second.hi);
+      (void)hipFree(kv.second.lo);
+      for (auto& s : kv.second.small) (void)hipFree(s.second);
+    }
+    for (auto& kv : coset_cache) {
+      (void)hipFree(kv.second.first);
+      (void)hipFree(kv.second.second);
+    }
+    cache.clear();
+    coset_cache.clear();
+  }
+};
+
+}  // namespace zkpoa

@@ -1,0 +1,672 @@
+// Groth16 prove on the device: zkey/wtns container parsing, device-resident proving key,
+// buildABC -> coset NTT chain -> joinABC -> five MSMs -> randomised assembly -> JSON.
+//
+// This is what runs behind the reference's exec boundary scripts/g16_prove.sh:248-252
+// (`prover <zkey> <wtns> <proof.json> <public.json>`); algorithm per snarkjs 0.7.2
+// groth16_prove.js as restated in SURVEY.md 3.2 / 8c (the reference vendors no prover source).
+#include "abc.hip.h"
+#include "msm.hip.h"
+#include "ntt.hip.h"
+#include "zkpoa_internal.hpp"
+
+#include <fcntl.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <map>
+#include <mutex>
+#include <thread>
+
+using namespace zkpoa;
+
+namespace {
+
+struct ProverError : std::runtime_error {
+  int code;
+  ProverError(int c, const std::string& s) : std::runtime_error(s), code(c) {}
+};
+
+// ---- binfile container: magic[4] u32 version u32 nSections {u32 id u64 len payload}*
+struct Section {
+  const uint8_t* p = nullptr;
+  uint64_t len = 0;
+};
+typedef std::map<uint32_t, Section> Sections;
+
+uint32_t rd_u32(const uint8_t* p) {
+  uint32_t v;
+  memcpy(&v, p, 4);
+  return v;
+}
+uint64_t rd_u64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+
+Sections parse_binfile(const uint8_t* buf, uint64_t size, const char* magic, uint32_t max_version) {
+  if (size < 12 || memcmp(buf, magic, 4) != 0)
+    throw ProverError(PROVER_ERROR, std::string(magic) + " file: invalid file format (bad magic)");
+  uint32_t version = rd_u32(buf + 4), nsec = rd_u32(buf + 8);
+  if (version > max_version) throw ProverError(PROVER_ERROR, std::string(magic) + " file: version not supported");
+  Sections out;
+  uint64_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > size) throw ProverError(PROVER_ERROR, std::string(magic) + " file: truncated section table");
+    uint32_t id = rd_u32(buf + pos);
+    uint64_t len = rd_u64(buf + pos + 4);
+    pos += 12;
+    if (len > size - pos) throw ProverError(PROVER_ERROR, std::string(magic) + " file: truncated section");
+    if (!out.count(id)) out[id] = Section{buf + pos, len};
+    pos += len;
+  }
+  return out;
+}
+
+const Section& need(const Sections& s, uint32_t id, const char* what) {
+  auto it = s.find(id);
+  if (it == s.end()) throw ProverError(PROVER_ERROR, std::string("missing section ") + what);
+  return it->second;
+}
+
+const uint8_t kQ[32] = {0x47, 0xfd, 0x7c, 0xd8, 0x16, 0x8c, 0x20, 0x3c, 0x8d, 0xca, 0x71, 0x68, 0x91, 0x6a, 0x81, 0x97,
+                        0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+const uint8_t kR[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                        0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+
+void* dev_upload(const void* src, size_t bytes) {
+  void* d = nullptr;
+  ZK_HIP(hipMalloc(&d, bytes ? bytes : 1));
+  if (bytes) ZK_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+  return d;
+}
+
+}  // namespace
+
+// ---- device-resident proving key -------------------------------------------------------------------
+struct zkpoa_zkey {
+  uint32_t nVars = 0, nPublic = 0, domain = 0, power = 0;
+  uint64_t nCoefs = 0;
+  Affine<HFq> alpha1, beta1, delta1;
+  Affine<HFq2> beta2, delta2;
+  void *dA = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dC = nullptr, *dH = nullptr;
+  uint32_t* d_row_ptr = nullptr;
+  uint32_t* d_sig = nullptr;
+  void* d_vals = nullptr;
+  void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
+  void* d_witness = nullptr;  // nVars * 32 B
+  void release() {
+    void* ptrs[] = {dA, dB1, dB2, dC, dH, d_row_ptr, d_sig, d_vals, d_abc, d_witness};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = nullptr;
+    d_row_ptr = d_sig = nullptr;
+  }
+};
+
+namespace {
+
+zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size) {
+  Sections secs = parse_binfile(buf, size, "zkey", 2);
+  const Section& s1 = need(secs, 1, "1 (protocol)");
+  if (s1.len < 4 || rd_u32(s1.p) != 1) throw ProverError(PROVER_ERROR, "zkey file is not groth16");
+  const Section& s2 = need(secs, 2, "2 (groth16 header)");
+  const uint64_t hdr = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128;
+  if (s2.len < hdr) throw ProverError(PROVER_ERROR, "zkey header too short");
+  const uint8_t* p = s2.p;
+  if (rd_u32(p) != 32 || memcmp(p + 4, kQ, 32) != 0) throw ProverError(PROVER_ERROR, "zkey curve not supported (q is not BN254)");
+  p += 36;
+  if (rd_u32(p) != 32 || memcmp(p + 4, kR, 32) != 0) throw ProverError(PROVER_ERROR, "zkey curve not supported (r is not BN254)");
+  p += 36;
+  std::unique_ptr<zkpoa_zkey> zk(new zkpoa_zkey());
+  zk->nVars = rd_u32(p);
+  zk->nPublic = rd_u32(p + 4);
+  zk->domain = rd_u32(p + 8);
+  p += 12;
+  if (zk->domain == 0 || (zk->domain & (zk->domain - 1))) throw ProverError(PROVER_ERROR, "zkey domainSize is not a power of two");
+  zk->power = 0;
+  while ((1u << zk->power) < zk->domain) zk->power++;
+  if (zk->power > 28) throw ProverError(PROVER_ERROR, "zkey domainSize exceeds 2^28");
+  if (zk->nPublic + 1 > zk->nVars) throw ProverError(PROVER_ERROR, "zkey nPublic >= nVars");
+  zk->alpha1 = h_affine_from_bytes<HFq>(p); p += 64;
+  zk->beta1 = h_affine_from_bytes<HFq>(p); p += 64;
+  zk->beta2 = h_affine_from_bytes<HFq2>(p); p += 128;
+  p += 128;  // gamma2: verifier only
+  zk->delta1 = h_affine_from_bytes<HFq>(p); p += 64;
+  zk->delta2 = h_affine_from_bytes<HFq2>(p);
+
+  const Section& s4 = need(secs, 4, "4 (coefficients)");
+  if (s4.len < 4) throw ProverError(PROVER_ERROR, "zkey coefficient section too short");
+  zk->nCoefs = rd_u32(s4.p);
+  if (s4.len != 4 + zk->nCoefs * 44) throw ProverError(PROVER_ERROR, "zkey coefficient section has the wrong size");
+  const Section& s5 = need(secs, 5, "5 (A points)");
+  const Section& s6 = need(secs, 6, "6 (B1 points)");
+  const Section& s7 = need(secs, 7, "7 (B2 points)");
+  const Section& s8 = need(secs, 8, "8 (C points)");
+  const Section& s9 = need(secs, 9, "9 (H points)");
+  const uint64_t m = zk->nVars, n = zk->domain;
+  if (s5.len != m * 64 || s6.len != m * 64 || s7.len != m * 128 || s8.len != (m - zk->nPublic - 1) * 64 ||
+      s9.len != n * 64)
+    throw ProverError(PROVER_ERROR, "zkey point section has the wrong size");
+
+  try {
+    zk->dA = dev_upload(s5.p, s5.len);
+    zk->dB1 = dev_upload(s6.p, s6.len);
+    zk->dB2 = dev_upload(s7.p, s7.len);
+    zk->dC = dev_upload(s8.p, s8.len);
+    zk->dH = dev_upload(s9.p, s9.len);
+    ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * n * 32));
+    ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
+
+    // CSR of the coefficient list by output row (2*c + m)
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    const uint32_t rows = 2 * zk->domain;
+    void* d_recs = dev_upload(s4.p + 4, zk->nCoefs * 44);
+    uint32_t *d_cnt = nullptr, *d_rank = nullptr, *d_bs = nullptr, *d_misc = nullptr;
+    ZK_HIP(hipMalloc(&d_cnt, (size_t)rows * 4));
+    ZK_HIP(hipMalloc(&d_rank, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
+    ZK_HIP(hipMalloc(&d_bs, ((size_t)rows / kScanTile + 2) * 4));
+    ZK_HIP(hipMalloc(&d_misc, 64));
+    ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
+    ZK_HIP(hipMalloc(&zk->d_sig, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
+    ZK_HIP(hipMalloc(&zk->d_vals, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 32));
+    ZK_HIP(hipMemsetAsync(d_cnt, 0, (size_t)rows * 4, st));
+    ZK_HIP(hipMemsetAsync(d_misc, 0, 64, st));
+    if (zk->nCoefs) {
+      uint32_t grid = (uint32_t)((zk->nCoefs + 255) / 256);
+      hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
+                         zk->domain, zk->nVars, d_cnt, d_rank, d_misc + 4);
+      scan_u32(st, d_cnt, rows, 0, 0, zk->d_row_ptr, d_bs, d_misc, nullptr);
+      hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
+                         (const uint32_t*)zk->d_row_ptr, (const uint32_t*)d_rank, zk->d_sig, zk->d_vals);
+    } else {
+      ZK_HIP(hipMemsetAsync(zk->d_row_ptr, 0, ((size_t)rows + 1) * 4, st));
+    }
+    uint32_t herr[2] = {0, 0};
+    ZK_HIP(hipMemcpyAsync(herr, d_misc + 4, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    (void)hipFree(d_recs);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_rank);
+    (void)hipFree(d_bs);
+    (void)hipFree(d_misc);
+    if (herr[0]) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
+    ntt_prepare(ctx, st, zk->power);
+    ZK_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    zk->release();
+    throw;
+  }
+  return zk.release();
+}
+
+// H-scalar chain on lane.stream: A_T,B_T,C_T -> odd coset -> P (standard form) left in abc[0 .. n)
+void h_chain(zkpoa_context* ctx, hipStream_t st, const uint32_t* row_ptr, const uint32_t* sig, const void* vals,
+             const void* d_witness, uint32_t domain, uint32_t power, void* d_abc) {
+  char* A = reinterpret_cast<char*>(d_abc);
+  char* B = A + (size_t)domain * 32;
+  char* C = B + (size_t)domain * 32;
+  uint32_t grid = (domain + 255) / 256;
+  hipLaunchKernelGGL(abc_rows_kernel, dim3(grid), dim3(256), 0, st, row_ptr, sig, vals, d_witness, domain, (void*)A,
+                     (void*)B, (void*)C);
+  ntt_to_odd_coset(ctx, st, A, power);
+  ntt_to_odd_coset(ctx, st, B, power);
+  ntt_to_odd_coset(ctx, st, C, power);
+  hipLaunchKernelGGL(abc_join_kernel, dim3(grid), dim3(256), 0, st, (void*)A, (const void*)B, (const void*)C, domain);
+}
+
+HFr hfr_from_le(const uint8_t* le) { return HFr::from_bytes(le); }
+
+void random_scalar(uint8_t out[32]) {
+  int fd = open("/dev/urandom", O_RDONLY);
+  if (fd < 0) throw ProverError(PROVER_ERROR, "cannot open /dev/urandom");
+  ssize_t got = read(fd, out, 32);
+  close(fd);
+  if (got != 32) throw ProverError(PROVER_ERROR, "short read from /dev/urandom");
+  out[31] &= 0x1f;  // < 2^253 < r
+}
+
+bool parse_decimal_mod_r(const char* s, uint8_t out[32]) {
+  if (!s || !*s) return false;
+  HFr acc = HFr::zero(), ten = HFr::from_u64(10);
+  for (const char* c = s; *c; c++) {
+    if (*c < '0' || *c > '9') return false;
+    acc = acc * ten + HFr::from_u64((uint64_t)(*c - '0'));
+  }
+  acc.from_mont().to_bytes(out);
+  return true;
+}
+
+struct WtnsView {
+  const uint8_t* values = nullptr;
+  uint32_t n = 0;
+};
+
+WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
+  Sections secs = parse_binfile(buf, size, "wtns", 2);
+  const Section& s1 = need(secs, 1, "1 (wtns header)");
+  if (s1.len < 40 || rd_u32(s1.p) != 32) throw ProverError(PROVER_ERROR, "wtns header: unsupported field size");
+  if (memcmp(s1.p + 4, kR, 32) != 0)
+    throw ProverError(PROVER_ERROR, "Curve of the witness does not match the curve of the proving key");
+  WtnsView w;
+  w.n = rd_u32(s1.p + 36);
+  const Section& s2 = need(secs, 2, "2 (wtns values)");
+  if (s2.len != (uint64_t)w.n * 32) throw ProverError(PROVER_ERROR, "wtns value section has the wrong size");
+  w.values = s2.p;
+  return w;
+}
+
+void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
+                const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
+                uint64_t public_cap) {
+  auto t0 = std::chrono::steady_clock::now();
+  WtnsView w = parse_wtns(wtns, wtns_size);
+  if (w.n != zk->nVars)
+    throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
+                                                         ", witness: " + std::to_string(w.n));
+  if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+  uint8_t rb[32], sb[32];
+  if (r_le) memcpy(rb, r_le, 32); else random_scalar(rb);
+  if (s_le) memcpy(sb, s_le, 32); else random_scalar(sb);
+
+  Lane& l0 = ctx->dev.lanes[0];
+  ZK_HIP(hipMemcpyAsync(zk->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, l0.stream));
+  ZK_HIP(hipStreamSynchronize(l0.stream));
+
+  // four witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back)
+  uint8_t outA[64], outB1[64], outB2[128], outC[64], outH[64];
+  std::exception_ptr errs[4];
+  float msm_ms[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  const char* wit = reinterpret_cast<const char*>(zk->d_witness);
+  const uint64_t nC = (uint64_t)zk->nVars - zk->nPublic - 1;
+  auto guarded = [&](int slot, std::function<void()> fn) {
+    return std::thread([&, slot, fn] {
+      try {
+        ZK_HIP(hipSetDevice(ctx->dev.device));
+        fn();
+      } catch (...) {
+        errs[slot] = std::current_exception();
+      }
+    });
+  };
+  auto tm0 = std::chrono::steady_clock::now();
+  std::thread tA = guarded(0, [&] { msm_run_g1(ctx, 1, zk->dA, wit, zk->nVars, outA, msm_ms[1]); });
+  std::thread tB1 = guarded(1, [&] { msm_run_g1(ctx, 2, zk->dB1, wit, zk->nVars, outB1, msm_ms[2]); });
+  std::thread tB2 = guarded(2, [&] { msm_run_g2(ctx, 3, zk->dB2, wit, zk->nVars, outB2, msm_ms[3]); });
+  std::thread tC = guarded(3, [&] {
+    msm_run_g1(ctx, 4, zk->dC, wit + (size_t)(zk->nPublic + 1) * 32, nC, outC, msm_ms[4]);
+  });
+
+  std::exception_ptr main_err;
+  try {
+    ZK_HIP(hipEventRecord(ctx->ev_a[5], l0.stream));
+    h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_witness, zk->domain, zk->power, zk->d_abc);
+    ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
+    msm_run_g1(ctx, 0, zk->dH, zk->d_abc, zk->domain, outH, msm_ms[0]);
+    ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
+  } catch (...) {
+    main_err = std::current_exception();
+  }
+  tA.join();
+  tB1.join();
+  tB2.join();
+  tC.join();
+  if (main_err) std::rethrow_exception(main_err);
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+  auto tm1 = std::chrono::steady_clock::now();
+
+  // randomised assembly (groth16_prove.js tail)
+  uint64_t rk[4], sk[4], nrs[4];
+  memcpy(rk, rb, 32);
+  memcpy(sk, sb, 32);
+  HFr rs = hfr_from_le(rb).to_mont() * hfr_from_le(sb).to_mont();
+  rs.neg().from_mont().to_bytes(nrs);
+
+  XYZZ<HFq> d1 = XYZZ<HFq>::from_affine(zk->delta1);
+  XYZZ<HFq2> d2 = XYZZ<HFq2>::from_affine(zk->delta2);
+  XYZZ<HFq> pi_a = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outA));
+  xyzz_add_affine(pi_a, zk->alpha1, false);
+  xyzz_add(pi_a, h_mul(d1, rk));
+  XYZZ<HFq2> pi_b = XYZZ<HFq2>::from_affine(h_affine_from_bytes<HFq2>(outB2));
+  xyzz_add_affine(pi_b, zk->beta2, false);
+  xyzz_add(pi_b, h_mul(d2, sk));
+  XYZZ<HFq> pib1 = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outB1));
+  xyzz_add_affine(pib1, zk->beta1, false);
+  xyzz_add(pib1, h_mul(d1, sk));
+  XYZZ<HFq> pi_c = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outC));
+  xyzz_add_affine(pi_c, h_affine_from_bytes<HFq>(outH), false);
+  xyzz_add(pi_c, h_mul(pi_a, sk));
+  xyzz_add(pi_c, h_mul(pib1, rk));
+  xyzz_add(pi_c, h_mul(d1, nrs));
+
+  h_affine_to_bytes<HFq>(h_to_affine(pi_a), proof_points);
+  h_affine_to_bytes<HFq2>(h_to_affine(pi_b), proof_points + 64);
+  h_affine_to_bytes<HFq>(h_to_affine(pi_c), proof_points + 192);
+  memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
+
+  auto t1 = std::chrono::steady_clock::now();
+  ctx->ms[4] = std::chrono::duration<float, std::milli>(tm1 - tm0).count();
+  ctx->ms[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  ctx->ms[0] = msm_ms[0][0];
+  ctx->ms[1] = msm_ms[0][1];
+}
+
+// ---- JSON (byte formats pinned by the reference's committed fixtures) --------
+std::string fq_dec(const uint8_t* le_mont) { return HFq::from_bytes(le_mont).to_dec(); }
+bool all_zero(const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; i++)
+    if (p[i]) return false;
+  return true;
+}
+
+std::string proof_json(const uint8_t pts[256], int style) {
+  // coordinates as decimal strings
+  std::string a[3], b[3][2], c[3];
+  auto g1 = [&](const uint8_t* p, std::string out[3]) {
+    if (all_zero(p, 64)) { out[0] = "0"; out[1] = "1"; out[2] = "0"; return; }
+    out[0] = fq_dec(p); out[1] = fq_dec(p + 32); out[2] = "1";
+  };
+  g1(pts, a);
+  g1(pts + 192, c);
+  const uint8_t* pb = pts + 64;
+  if (all_zero(pb, 128)) {
+    b[0][0] = "0"; b[0][1] = "0"; b[1][0] = "1"; b[1][1] = "0"; b[2][0] = "0"; b[2][1] = "0";
+  } else {
+    b[0][0] = fq_dec(pb); b[0][1] = fq_dec(pb + 32); b[1][0] = fq_dec(pb + 64); b[1][1] = fq_dec(pb + 96);
+    b[2][0] = "1"; b[2][1] = "0";
+  }
+  std::string o;
+  auto q = [](const std::string& s) { return "\"" + s + "\""; };
+  if (style == 0) {  // rapidsnark / nlohmann dump(): one line, no spaces
+    o += "{\"pi_a\":[" + q(a[0]) + "," + q(a[1]) + "," + q(a[2]) + "],";
+    o += "\"pi_b\":[[" + q(b[0][0]) + "," + q(b[0][1]) + "],[" + q(b[1][0]) + "," + q(b[1][1]) + "],[" + q(b[2][0]) +
+         "," + q(b[2][1]) + "]],";
+    o += "\"pi_c\":[" + q(c[0]) + "," + q(c[1]) + "," + q(c[2]) + "],";
+    o += "\"protocol\":\"groth16\"}";
+  } else {  // snarkjs: JSON.stringify(obj, null, 1)
+    auto g1s = [&](const char* key, const std::string v[3]) {
+      return std::string(" \"") + key + "\": [\n  " + q(v[0]) + ",\n  " + q(v[1]) + ",\n  " + q(v[2]) + "\n ],\n";
+    };
+    o += "{\n";
+    o += g1s("pi_a", a);
+    o += " \"pi_b\": [\n";
+    for (int i = 0; i < 3; i++) {
+      o += "  [\n   " + q(b[i][0]) + ",\n   " + q(b[i][1]) + "\n  ]";
+      o += (i < 2) ? ",\n" : "\n";
+    }
+    o += " ],\n";
+    o += g1s("pi_c", c);
+    o += " \"protocol\": \"groth16\",\n \"curve\": \"bn128\"\n}";
+  }
+  return o;
+}
+
+std::string public_json(const uint8_t* pub, uint64_t n, int style) {
+  std::string o;
+  if (style == 0) {
+    o = "[";
+    for (uint64_t i = 0; i < n; i++) {
+      HFr v = HFr::from_bytes(pub + 32 * i).to_mont();
+      o += (i ? ",\"" : "\"") + v.to_dec() + "\"";
+    }
+    o += "]";
+  } else {
+    if (n == 0) return "[]";
+    o = "[\n";
+    for (uint64_t i = 0; i < n; i++) {
+      HFr v = HFr::from_bytes(pub + 32 * i).to_mont();
+      o += " \"" + v.to_dec() + "\"" + (i + 1 < n ? ",\n" : "\n");
+    }
+    o += "]";
+  }
+  return o;
+}
+
+int emit(const std::string& s, char* buffer, unsigned long* size) {
+  if (!size) return PROVER_ERROR;
+  unsigned long needed = (unsigned long)s.size() + 1;
+  if (!buffer || *size < needed) {
+    *size = needed;
+    return PROVER_ERROR_SHORT_BUFFER;
+  }
+  memcpy(buffer, s.c_str(), needed);
+  *size = needed;
+  return PROVER_OK;
+}
+
+std::mutex g_ctx_mutex;
+zkpoa_context* g_ctx = nullptr;
+
+zkpoa_context* process_context(std::string& err) {
+  std::lock_guard<std::mutex> lk(g_ctx_mutex);
+  if (g_ctx) return g_ctx;
+  int dev = 0;
+  if (const char* e = getenv("ZKPOA_DEVICE")) dev = atoi(e);
+  char msg[512] = {0};
+  if (zkpoa_context_create(dev, &g_ctx, msg, sizeof(msg)) != PROVER_OK) {
+    err = msg;
+    g_ctx = nullptr;
+  }
+  return g_ctx;
+}
+
+int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+             unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+             unsigned long error_msg_maxsize) {
+  std::string err;
+  zkpoa_context* ctx = process_context(err);
+  if (!ctx) {
+    set_err(error_msg, error_msg_maxsize, err);
+    return PROVER_ERROR;
+  }
+  zkpoa_zkey* zk = nullptr;
+  int rc = PROVER_OK;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    zk = zkey_load_impl(ctx, zkey, zkey_size);
+    uint8_t rb[32], sb[32];
+    const uint8_t *rp = nullptr, *sp = nullptr;
+    if (const char* e = getenv("ZKPOA_R")) {
+      if (!parse_decimal_mod_r(e, rb)) throw ProverError(PROVER_ERROR, "ZKPOA_R is not a decimal number");
+      rp = rb;
+    }
+    if (const char* e = getenv("ZKPOA_S")) {
+      if (!parse_decimal_mod_r(e, sb)) throw ProverError(PROVER_ERROR, "ZKPOA_S is not a decimal number");
+      sp = sb;
+    }
+    int style = 0;
+    if (const char* e = getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
+    uint8_t pts[256];
+    std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
+    prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
+    std::string pj = proof_json(pts, style), uj = public_json(pub.data(), zk->nPublic, style);
+    int r1 = emit(pj, proof_buffer, proof_size);
+    int r2 = emit(uj, public_buffer, public_size);
+    if (r1 != PROVER_OK || r2 != PROVER_OK) {
+      rc = PROVER_ERROR_SHORT_BUFFER;
+      set_err(error_msg, error_msg_maxsize, "output buffer too small");
+    }
+    if (getenv("ZKPOA_VERBOSE")) {
+      fprintf(stderr, "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | h-chain %.2f ms, msm phase %.2f ms, prove %.2f ms\n",
+              zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
+    }
+  } catch (const ProverError& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = e.code;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR;
+  }
+  if (zk) {
+    zk->release();
+    delete zk;
+  }
+  return rc;
+}
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------
+#define ZK_PROVER_CATCH(ctx)          \
+  catch (const ProverError& e) {      \
+    (ctx)->last_error = e.what();     \
+    return e.code;                    \
+  }                                   \
+  catch (const std::exception& e) {   \
+    (ctx)->last_error = e.what();     \
+    return PROVER_ERROR;              \
+  }
+
+extern "C" int zkpoa_zkey_load(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size, zkpoa_zkey** out) {
+  if (!ctx || !out || !zkey_buffer) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" void zkpoa_zkey_free(zkpoa_context* ctx, zkpoa_zkey* zkey) {
+  if (!zkey) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->dev.device);
+    (void)hipDeviceSynchronize();
+  }
+  zkey->release();
+  delete zkey;
+}
+
+extern "C" int zkpoa_zkey_info(const zkpoa_zkey* zkey, uint64_t out[4]) {
+  if (!zkey || !out) return PROVER_ERROR;
+  out[0] = zkey->nVars;
+  out[1] = zkey->nPublic;
+  out[2] = zkey->domain;
+  out[3] = zkey->nCoefs;
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer, unsigned long wtns_size,
+                           const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
+                           unsigned long public_capacity) {
+  if (!ctx || !zkey || !wtns_buffer || !proof_points) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    uint8_t dummy[1];
+    prove_impl(ctx, zkey, reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, r_le, s_le, proof_points,
+               public_le ? public_le : dummy, public_le ? public_capacity : (zkey->nPublic ? 0 : 1));
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_proof_to_json(const uint8_t proof_points[256], int style, char* buffer, unsigned long* size) {
+  if (!proof_points) return PROVER_ERROR;
+  return emit(proof_json(proof_points, style), buffer, size);
+}
+
+extern "C" int zkpoa_public_to_json(const uint8_t* public_le, unsigned long n_public, int style, char* buffer,
+                                    unsigned long* size) {
+  if (!public_le && n_public) return PROVER_ERROR;
+  return emit(public_json(public_le, n_public, style), buffer, size);
+}
+
+extern "C" int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned long coeffs_size, const void* witness,
+                               uint64_t n_vars, unsigned log_domain, void* out) {
+  if (!ctx || !coeffs || !witness || !out) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (log_domain > 28) throw ProverError(PROVER_ERROR, "h_scalars: log_domain > 28");
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(coeffs);
+    if (coeffs_size < 4) throw ProverError(PROVER_ERROR, "h_scalars: coefficient payload too short");
+    uint64_t ncoef = rd_u32(cb);
+    if (coeffs_size != 4 + ncoef * 44) throw ProverError(PROVER_ERROR, "h_scalars: coefficient payload has the wrong size");
+    const uint32_t domain = 1u << log_domain, rows = 2 * domain;
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    DevBuf recs(ncoef * 44), cnt((size_t)rows * 4), rank((ncoef ? ncoef : 1) * 4), bs(((size_t)rows / kScanTile + 2) * 4),
+        misc(64), row_ptr(((size_t)rows + 1) * 4), sig((ncoef ? ncoef : 1) * 4), vals((ncoef ? ncoef : 1) * 32),
+        abc((size_t)3 * domain * 32), wit(n_vars * 32);
+    ZK_HIP(hipMemcpy(recs.p, cb + 4, ncoef * 44, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(wit.p, witness, n_vars * 32, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)rows * 4, st));
+    ZK_HIP(hipMemsetAsync(misc.p, 0, 64, st));
+    ZK_HIP(hipMemsetAsync(row_ptr.p, 0, ((size_t)rows + 1) * 4, st));
+    if (ncoef) {
+      uint32_t grid = (uint32_t)((ncoef + 255) / 256);
+      hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)recs.p, ncoef, domain,
+                         (uint32_t)n_vars, (uint32_t*)cnt.p, (uint32_t*)rank.p, (uint32_t*)misc.p + 4);
+      scan_u32(st, (const uint32_t*)cnt.p, rows, 0, 0, (uint32_t*)row_ptr.p, (uint32_t*)bs.p, (uint32_t*)misc.p,
+               nullptr);
+      hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)recs.p, ncoef,
+                         (const uint32_t*)row_ptr.p, (const uint32_t*)rank.p, (uint32_t*)sig.p, vals.p);
+    }
+    uint32_t herr = 0;
+    ZK_HIP(hipMemcpyAsync(&herr, (uint32_t*)misc.p + 4, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (herr) throw ProverError(PROVER_ERROR, "h_scalars: coefficient record out of range");
+    ntt_prepare(ctx, st, log_domain);
+    ZK_HIP(hipEventRecord(ctx->ev_a[5], st));
+    h_chain(ctx, st, (const uint32_t*)row_ptr.p, (const uint32_t*)sig.p, vals.p, wit.p, domain, log_domain, abc.p);
+    ZK_HIP(hipEventRecord(ctx->ev_b[5], st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
+    ZK_HIP(hipMemcpy(out, abc.p, (size_t)domain * 32, hipMemcpyDeviceToHost));
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer,
+                              unsigned long wtns_size, char* proof_buffer, unsigned long* proof_size,
+                              char* public_buffer, unsigned long* public_size, char* error_msg,
+                              unsigned long error_msg_maxsize) {
+  if (!zkey_buffer || !wtns_buffer || !proof_size || !public_size) {
+    set_err(error_msg, error_msg_maxsize, "null argument");
+    return PROVER_ERROR;
+  }
+  return one_shot(reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size,
+                  reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer, proof_size, public_buffer,
+                  public_size, error_msg, error_msg_maxsize);
+}
+
+extern "C" int groth16_prover_zkey_file(const char* zkey_file_path, const void* wtns_buffer, unsigned long wtns_size,
+                                        char* proof_buffer, unsigned long* proof_size, char* public_buffer,
+                                        unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize) {
+  if (!zkey_file_path || !wtns_buffer || !proof_size || !public_size) {
+    set_err(error_msg, error_msg_maxsize, "null argument");
+    return PROVER_ERROR;
+  }
+  int fd = open(zkey_file_path, O_RDONLY);
+  if (fd < 0) {
+    set_err(error_msg, error_msg_maxsize, std::string("cannot open zkey file ") + zkey_file_path);
+    return PROVER_ERROR;
+  }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size == 0) {
+    close(fd);
+    set_err(error_msg, error_msg_maxsize, std::string("cannot stat zkey file ") + zkey_file_path);
+    return PROVER_ERROR;
+  }
+  void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) {
+    set_err(error_msg, error_msg_maxsize, std::string("cannot mmap zkey file ") + zkey_file_path);
+    return PROVER_ERROR;
+  }
+  int rc = one_shot(reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size,
+                    reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer, proof_size, public_buffer,
+                    public_size, error_msg, error_msg_maxsize);
+  munmap(map, (size_t)sb.st_size);
+  return rc;
+}

@@ -44,6 +44,7 @@ extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
     if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
   }
+  ntt_release(ctx);
   ctx->dev.destroy();
   delete ctx;
 }
@@ -76,14 +77,14 @@ extern "C" int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, cons
                                    uint8_t out[64]) {
   ZK_API_BEGIN(ctx)
   check_n(n);
-  msm_run_g1(ctx, 0, d_bases, d_scalars, n, out);
+  msm_run_g1(ctx, 0, d_bases, d_scalars, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
 extern "C" int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n,
                                    uint8_t out[128]) {
   ZK_API_BEGIN(ctx)
   check_n(n);
-  msm_run_g2(ctx, 0, d_bases, d_scalars, n, out);
+  msm_run_g2(ctx, 0, d_bases, d_scalars, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
 extern "C" int zkpoa_msm_g1(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[64]) {
@@ -92,7 +93,7 @@ extern "C" int zkpoa_msm_g1(zkpoa_context* ctx, const void* bases, const void* s
   DevBuf db(n * 64), ds(n * 32);
   ZK_HIP(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
   ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
-  msm_run_g1(ctx, 0, db.p, ds.p, n, out);
+  msm_run_g1(ctx, 0, db.p, ds.p, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
 extern "C" int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* scalars, uint64_t n, uint8_t out[128]) {
@@ -101,7 +102,7 @@ extern "C" int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* s
   DevBuf db(n * 128), ds(n * 32);
   ZK_HIP(hipMemcpy(db.p, bases, n * 128, hipMemcpyHostToDevice));
   ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
-  msm_run_g2(ctx, 0, db.p, ds.p, n, out);
+  msm_run_g2(ctx, 0, db.p, ds.p, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
 

@@ -7,8 +7,13 @@
 #include <string>
 #include <vector>
 
+namespace zkpoa {
+struct NttEngine;
+}
+
 struct zkpoa_context {
   zkpoa::DeviceCtx dev;
+  zkpoa::NttEngine* ntt = nullptr;
   std::string last_error;
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int opt_msm_c = 0;
@@ -31,12 +36,19 @@ struct DevBuf {  // RAII device allocation for the host-buffer entry points
 
 
 // per-group entry points, each compiled in its own translation unit (msm_g1.hip, msm_g2.hip, ...)
-void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out);
-void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out);
+void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
+                float* ms2);
+void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
+                float* ms2);
 void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
 void gen_bases_g2(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
+// ntt.hip
+void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k);  // builds twiddle tables (hipMalloc) once per k
+void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k);
+void ntt_natural(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
+void ntt_release(zkpoa_context* ctx);
 }  // namespace zkpoa
 
 #define ZK_API_BEGIN(ctx)  \
