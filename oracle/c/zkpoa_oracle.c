@@ -1,0 +1,469 @@
+/* ORACLE (test infrastructure, not product code) -- plain-C restatement of the Groth16 prove path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (zk-proof-of-assets_amd/) never links or calls it.
+ *
+ * Restates, for the CPU, what the reference's external provers compute behind
+ * scripts/g16_prove.sh:248-259 (rapidsnark `prover` / `snarkjs groth16 prove`): the algorithm
+ * of snarkjs 0.7.2 groth16_prove.js (pnpm-lock.yaml:2231) over ffjavascript 0.2.62 field/curve
+ * semantics (pnpm-lock.yaml:1406) -- none of which is vendored under /root/reference -- as
+ * specified in SURVEY.md 3.2 and 8c. Function by function:
+ *   orc_h_scalars   = buildABC1 + 3 x (Fr.ifft, batchApplyKey(1, inc), Fr.fft) + joinABC
+ *   orc_msm_g1/g2   = G1/G2.multiExpAffine (here: textbook Pippenger, unsigned c-bit windows,
+ *                     threaded by window like rapidsnark's ParallelMultiexp)
+ *   orc_prove       = groth16Prove (five MSMs + randomised assembly)
+ * Pinning: this file is checked against oracle/py (big-int Python), which is itself pinned by the
+ * reference's committed proof/vkey fixtures through the pairing verifier; the (zkey, wtns) -> proof
+ * map has no golden vector in the reference ("prover parity unpinned" beyond that chain).
+ *
+ * Arithmetic: 4 x u64 limbs, unsigned __int128 products, Montgomery R = 2^256. Written
+ * independently of the product's host_field.hpp (different reduction schedule, Jacobian
+ * instead of XYZZ coordinates) so the two do not share bugs.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t v[4]; } fe;           /* field element, Montgomery form unless said otherwise */
+typedef struct { const uint64_t* p; uint64_t inv; fe one; fe r2; } field;
+
+static const uint64_t QP[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t RP[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const field FQ = {QP, 0x87d20782e4866389ull,
+  {{0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full}},
+  {{0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full}}};
+static const field FR = {RP, 0xc2e1f593efffffffull,
+  {{0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full}},
+  {{0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull}}};
+
+static int fe_is_zero(const fe* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static int fe_eq(const fe* a, const fe* b) { return memcmp(a, b, 32) == 0; }
+static int geq(const uint64_t* a, const uint64_t* p) {
+  for (int i = 3; i >= 0; i--) { if (a[i] > p[i]) return 1; if (a[i] < p[i]) return 0; }
+  return 1;
+}
+static void sub_p(uint64_t* a, const uint64_t* p) {
+  u128 b = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - p[i] - b; a[i] = (uint64_t)d; b = (d >> 64) & 1; }
+}
+static void fe_add(const field* F, fe* r, const fe* a, const fe* b) {
+  u128 c = 0; fe t;
+  for (int i = 0; i < 4; i++) { c += (u128)a->v[i] + b->v[i]; t.v[i] = (uint64_t)c; c >>= 64; }
+  if (geq(t.v, F->p)) sub_p(t.v, F->p);
+  *r = t;
+}
+static void fe_sub(const field* F, fe* r, const fe* a, const fe* b) {
+  u128 bw = 0; fe t;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a->v[i] - b->v[i] - bw; t.v[i] = (uint64_t)d; bw = (d >> 64) & 1; }
+  if (bw) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t.v[i] + F->p[i]; t.v[i] = (uint64_t)c; c >>= 64; } }
+  *r = t;
+}
+static void fe_neg(const field* F, fe* r, const fe* a) { fe z = {{0, 0, 0, 0}}; if (fe_is_zero(a)) *r = *a; else fe_sub(F, r, &z, a); }
+/* Montgomery product: full 512-bit schoolbook product, then four reduction rounds (SOS) */
+static void fe_mul(const field* F, fe* r, const fe* a, const fe* b) {
+  uint64_t t[9] = {0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a->v[i] * b->v[j] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    t[i + 4] = (uint64_t)c;
+  }
+  for (int i = 0; i < 4; i++) {
+    uint64_t m = t[i] * F->inv; u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)m * F->p[j] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    for (int k = i + 4; k < 9 && c; k++) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+  }
+  fe o = {{t[4], t[5], t[6], t[7]}};
+  if (t[8] || geq(o.v, F->p)) sub_p(o.v, F->p);
+  *r = o;
+}
+static void fe_sqr(const field* F, fe* r, const fe* a) { fe_mul(F, r, a, a); }
+static void fe_to_mont(const field* F, fe* r, const fe* a) { fe_mul(F, r, a, &F->r2); }
+static void fe_from_mont(const field* F, fe* r, const fe* a) { fe o = {{1, 0, 0, 0}}; fe_mul(F, r, a, &o); }
+static void fe_pow(const field* F, fe* r, const fe* a, const uint64_t e[4]) {
+  fe res = F->one, base = *a;
+  for (int i = 0; i < 4; i++) for (int b = 0; b < 64; b++) {
+    if ((e[i] >> b) & 1) fe_mul(F, &res, &res, &base);
+    fe_sqr(F, &base, &base);
+  }
+  *r = res;
+}
+static void fe_inv(const field* F, fe* r, const fe* a) {
+  uint64_t e[4] = {F->p[0] - 2, F->p[1], F->p[2], F->p[3]};
+  fe_pow(F, r, a, e);
+}
+static void fe_from_u64(const field* F, fe* r, uint64_t x) { fe t = {{x, 0, 0, 0}}; fe_to_mont(F, r, &t); }
+
+/* ---- Fq2 = Fq[u]/(u^2+1) ---------------------------------------------------------------------- */
+typedef struct { fe c0, c1; } fe2;
+static void f2_add(fe2* r, const fe2* a, const fe2* b) { fe_add(&FQ, &r->c0, &a->c0, &b->c0); fe_add(&FQ, &r->c1, &a->c1, &b->c1); }
+static void f2_sub(fe2* r, const fe2* a, const fe2* b) { fe_sub(&FQ, &r->c0, &a->c0, &b->c0); fe_sub(&FQ, &r->c1, &a->c1, &b->c1); }
+static void f2_mul(fe2* r, const fe2* a, const fe2* b) {   /* schoolbook: 4 multiplications */
+  fe t0, t1, t2, t3, o0, o1;
+  fe_mul(&FQ, &t0, &a->c0, &b->c0); fe_mul(&FQ, &t1, &a->c1, &b->c1);
+  fe_mul(&FQ, &t2, &a->c0, &b->c1); fe_mul(&FQ, &t3, &a->c1, &b->c0);
+  fe_sub(&FQ, &o0, &t0, &t1); fe_add(&FQ, &o1, &t2, &t3);
+  r->c0 = o0; r->c1 = o1;
+}
+static int f2_is_zero(const fe2* a) { return fe_is_zero(&a->c0) && fe_is_zero(&a->c1); }
+static int f2_eq(const fe2* a, const fe2* b) { return fe_eq(&a->c0, &b->c0) && fe_eq(&a->c1, &b->c1); }
+static void f2_inv(fe2* r, const fe2* a) {
+  fe n0, n1, d; fe_sqr(&FQ, &n0, &a->c0); fe_sqr(&FQ, &n1, &a->c1); fe_add(&FQ, &d, &n0, &n1); fe_inv(&FQ, &d, &d);
+  fe_mul(&FQ, &r->c0, &a->c0, &d); fe_mul(&FQ, &n0, &a->c1, &d); fe_neg(&FQ, &r->c1, &n0);
+}
+
+/* ---- generic Jacobian curve arithmetic over "K" = Fq (G1) or Fq2 (G2), via macros ---------------- */
+#define DEFINE_CURVE(PFX, K, K_ADD, K_SUB, K_MUL, K_ISZ, K_EQ, K_INV, K_ONE_INIT)                          \
+  typedef struct { K x, y; } PFX##_aff;            /* infinity = (0,0) */                                  \
+  typedef struct { K x, y, z; } PFX##_jac;         /* infinity: z = 0 */                                   \
+  static void PFX##_set_inf(PFX##_jac* p) { memset(p, 0, sizeof(*p)); }                                    \
+  static int PFX##_aff_is_inf(const PFX##_aff* p) { return K_ISZ(&p->x) && K_ISZ(&p->y); }                 \
+  static void PFX##_dbl(PFX##_jac* r, const PFX##_jac* p) {                                               \
+    if (K_ISZ(&p->z) || K_ISZ(&p->y)) { PFX##_set_inf(r); return; }                                        \
+    K a, b, c, d, e, f, t, x3, y3, z3;                                                                     \
+    K_MUL(&a, &p->x, &p->x); K_MUL(&b, &p->y, &p->y); K_MUL(&c, &b, &b);                                   \
+    K_ADD(&t, &p->x, &b); K_MUL(&t, &t, &t); K_SUB(&t, &t, &a); K_SUB(&t, &t, &c); K_ADD(&d, &t, &t);      \
+    K_ADD(&e, &a, &a); K_ADD(&e, &e, &a); K_MUL(&f, &e, &e);                                               \
+    K_SUB(&x3, &f, &d); K_SUB(&x3, &x3, &d);                                                               \
+    K_SUB(&t, &d, &x3); K_MUL(&y3, &e, &t);                                                                \
+    K_ADD(&c, &c, &c); K_ADD(&c, &c, &c); K_ADD(&c, &c, &c); K_SUB(&y3, &y3, &c);                          \
+    K_MUL(&z3, &p->y, &p->z); K_ADD(&z3, &z3, &z3);                                                        \
+    r->x = x3; r->y = y3; r->z = z3;                                                                       \
+  }                                                                                                        \
+  /* r = p + q (q affine) */                                                                               \
+  static void PFX##_madd(PFX##_jac* r, const PFX##_jac* p, const PFX##_aff* q) {                          \
+    if (PFX##_aff_is_inf(q)) { *r = *p; return; }                                                          \
+    if (K_ISZ(&p->z)) { r->x = q->x; r->y = q->y; K one = K_ONE_INIT; r->z = one; return; }                \
+    K z2, u2, s2, h, rr, hh, hhh, v, t, x3, y3, z3;                                                        \
+    K_MUL(&z2, &p->z, &p->z); K_MUL(&u2, &q->x, &z2); K_MUL(&s2, &p->z, &z2); K_MUL(&s2, &s2, &q->y);      \
+    K_SUB(&h, &u2, &p->x); K_SUB(&rr, &s2, &p->y);                                                         \
+    if (K_ISZ(&h)) { if (K_ISZ(&rr)) { PFX##_dbl(r, p); } else { PFX##_set_inf(r); } return; }             \
+    K_MUL(&hh, &h, &h); K_MUL(&hhh, &hh, &h); K_MUL(&v, &p->x, &hh);                                       \
+    K_MUL(&x3, &rr, &rr); K_SUB(&x3, &x3, &hhh); K_SUB(&x3, &x3, &v); K_SUB(&x3, &x3, &v);                 \
+    K_SUB(&t, &v, &x3); K_MUL(&y3, &rr, &t); K_MUL(&t, &p->y, &hhh); K_SUB(&y3, &y3, &t);                  \
+    K_MUL(&z3, &p->z, &h);                                                                                 \
+    r->x = x3; r->y = y3; r->z = z3;                                                                       \
+  }                                                                                                        \
+  static void PFX##_add(PFX##_jac* r, const PFX##_jac* p, const PFX##_jac* q) {                           \
+    if (K_ISZ(&q->z)) { *r = *p; return; }                                                                 \
+    if (K_ISZ(&p->z)) { *r = *q; return; }                                                                 \
+    K z1z1, z2z2, u1, u2, s1, s2, h, rr, hh, hhh, v, t, x3, y3, z3;                                        \
+    K_MUL(&z1z1, &p->z, &p->z); K_MUL(&z2z2, &q->z, &q->z);                                                \
+    K_MUL(&u1, &p->x, &z2z2); K_MUL(&u2, &q->x, &z1z1);                                                    \
+    K_MUL(&s1, &q->z, &z2z2); K_MUL(&s1, &s1, &p->y); K_MUL(&s2, &p->z, &z1z1); K_MUL(&s2, &s2, &q->y);    \
+    K_SUB(&h, &u2, &u1); K_SUB(&rr, &s2, &s1);                                                             \
+    if (K_ISZ(&h)) { if (K_ISZ(&rr)) { PFX##_dbl(r, p); } else { PFX##_set_inf(r); } return; }             \
+    K_MUL(&hh, &h, &h); K_MUL(&hhh, &hh, &h); K_MUL(&v, &u1, &hh);                                         \
+    K_MUL(&x3, &rr, &rr); K_SUB(&x3, &x3, &hhh); K_SUB(&x3, &x3, &v); K_SUB(&x3, &x3, &v);                 \
+    K_SUB(&t, &v, &x3); K_MUL(&y3, &rr, &t); K_MUL(&t, &s1, &hhh); K_SUB(&y3, &y3, &t);                    \
+    K_MUL(&z3, &p->z, &q->z); K_MUL(&z3, &z3, &h);                                                         \
+    r->x = x3; r->y = y3; r->z = z3;                                                                       \
+  }                                                                                                        \
+  static void PFX##_to_aff(PFX##_aff* r, const PFX##_jac* p) {                                            \
+    if (K_ISZ(&p->z)) { memset(r, 0, sizeof(*r)); return; }                                                \
+    K zi, zi2, zi3; K_INV(&zi, &p->z); K_MUL(&zi2, &zi, &zi); K_MUL(&zi3, &zi2, &zi);                      \
+    K_MUL(&r->x, &p->x, &zi2); K_MUL(&r->y, &p->y, &zi3);                                                  \
+  }                                                                                                        \
+  static void PFX##_from_aff(PFX##_jac* r, const PFX##_aff* q) {                                          \
+    if (PFX##_aff_is_inf(q)) { PFX##_set_inf(r); return; }                                                 \
+    r->x = q->x; r->y = q->y; K one = K_ONE_INIT; r->z = one;                                              \
+  }                                                                                                        \
+  /* k * p, k = 4 x u64 standard form */                                                                   \
+  static void PFX##_mul(PFX##_jac* r, const PFX##_jac* p, const uint64_t k[4]) {                          \
+    PFX##_jac acc; PFX##_set_inf(&acc);                                                                    \
+    for (int i = 3; i >= 0; i--) for (int b = 63; b >= 0; b--) {                                           \
+      PFX##_dbl(&acc, &acc);                                                                               \
+      if ((k[i] >> b) & 1) PFX##_add(&acc, &acc, p);                                                       \
+    }                                                                                                      \
+    *r = acc;                                                                                              \
+  }
+
+static void q_add(fe* r, const fe* a, const fe* b) { fe_add(&FQ, r, a, b); }
+static void q_sub(fe* r, const fe* a, const fe* b) { fe_sub(&FQ, r, a, b); }
+static void q_mul(fe* r, const fe* a, const fe* b) { fe_mul(&FQ, r, a, b); }
+static void q_inv(fe* r, const fe* a) { fe_inv(&FQ, r, a); }
+#define FQ_ONE_INIT {{0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full}}
+#define FQ2_ONE_INIT {FQ_ONE_INIT, {{0, 0, 0, 0}}}
+DEFINE_CURVE(g1, fe, q_add, q_sub, q_mul, fe_is_zero, fe_eq, q_inv, FQ_ONE_INIT)
+DEFINE_CURVE(g2, fe2, f2_add, f2_sub, f2_mul, f2_is_zero, f2_eq, f2_inv, FQ2_ONE_INIT)
+
+/* ---- Pippenger MSM: unsigned c-bit windows, one thread per window stripe ------------------------- */
+static unsigned scalar_window(const uint64_t* k, unsigned bit, unsigned c) {
+  unsigned limb = bit >> 6, off = bit & 63;
+  if (limb > 3) return 0;
+  uint64_t v = k[limb] >> off;
+  if (off + c > 64 && limb < 3) v |= k[limb + 1] << (64 - off);
+  return (unsigned)(v & ((1ull << c) - 1));
+}
+static unsigned pick_c(uint64_t n) {
+  unsigned best = 1; double bc = 1e300;
+  for (unsigned c = 1; c <= 16; c++) {
+    double cost = (double)((254 + c - 1) / c) * ((double)n + 2.0 * (double)(1u << c));
+    if (cost < bc) { bc = cost; best = c; }
+  }
+  return best;
+}
+
+#define DEFINE_MSM(PFX, AFFSZ)                                                                             \
+  typedef struct { const PFX##_aff* bases; const uint64_t* scalars; uint64_t n; unsigned c, W, w0, wstep;  \
+                   PFX##_jac* win; } PFX##_job;                                                            \
+  static void* PFX##_worker(void* arg) {                                                                   \
+    PFX##_job* j = (PFX##_job*)arg;                                                                        \
+    size_t nb = (size_t)1 << j->c;                                                                         \
+    PFX##_jac* buckets = (PFX##_jac*)malloc(nb * sizeof(PFX##_jac));                                      \
+    for (unsigned w = j->w0; w < j->W; w += j->wstep) {                                                    \
+      memset(buckets, 0, nb * sizeof(PFX##_jac));                                                          \
+      for (uint64_t i = 0; i < j->n; i++) {                                                                \
+        unsigned d = scalar_window(j->scalars + 4 * i, w * j->c, j->c);                                    \
+        if (d) PFX##_madd(&buckets[d], &buckets[d], &j->bases[i]);                                         \
+      }                                                                                                    \
+      PFX##_jac run, sum; PFX##_set_inf(&run); PFX##_set_inf(&sum);                                        \
+      for (size_t b = nb - 1; b >= 1; b--) { PFX##_add(&run, &run, &buckets[b]); PFX##_add(&sum, &sum, &run); } \
+      j->win[w] = sum;                                                                                     \
+    }                                                                                                      \
+    free(buckets);                                                                                         \
+    return 0;                                                                                              \
+  }                                                                                                        \
+  /* bases: n affine Montgomery points (zkey wire format), scalars: n x 32 B standard form */              \
+  int orc_msm_##PFX(const void* bases, const void* scalars, uint64_t n, void* out, int nthreads) {         \
+    unsigned c = pick_c(n ? n : 1), W = (254 + c - 1) / c;                                                 \
+    if (nthreads < 1) nthreads = 1;                                                                        \
+    if ((unsigned)nthreads > W) nthreads = (int)W;                                                         \
+    PFX##_jac* win = (PFX##_jac*)calloc(W, sizeof(PFX##_jac));                                            \
+    PFX##_job* jobs = (PFX##_job*)calloc((size_t)nthreads, sizeof(PFX##_job));                            \
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));                               \
+    for (int t = 0; t < nthreads; t++) {                                                                   \
+      jobs[t] = (PFX##_job){(const PFX##_aff*)bases, (const uint64_t*)scalars, n, c, W, (unsigned)t,       \
+                            (unsigned)nthreads, win};                                                      \
+      if (t) pthread_create(&th[t], 0, PFX##_worker, &jobs[t]);                                            \
+    }                                                                                                      \
+    PFX##_worker(&jobs[0]);                                                                                \
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);                                             \
+    PFX##_jac acc; PFX##_set_inf(&acc);                                                                    \
+    for (int w = (int)W - 1; w >= 0; w--) {                                                                \
+      for (unsigned k = 0; k < c; k++) PFX##_dbl(&acc, &acc);                                              \
+      PFX##_add(&acc, &acc, &win[w]);                                                                      \
+    }                                                                                                      \
+    PFX##_aff r; PFX##_to_aff(&r, &acc); memcpy(out, &r, AFFSZ);                                           \
+    free(win); free(jobs); free(th);                                                                       \
+    return 0;                                                                                              \
+  }
+DEFINE_MSM(g1, 64)
+DEFINE_MSM(g2, 128)
+
+/* ---- generators and fixed-base multiplication ------------------------------------------------- */
+static void g1_gen(g1_aff* g) { fe_from_u64(&FQ, &g->x, 1); fe_from_u64(&FQ, &g->y, 2); }
+static void g2_gen(g2_aff* g) {
+  static const uint64_t c[4][4] = {   /* standard form, little-endian limbs */
+    {0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull},
+    {0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull},
+    {0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull},
+    {0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull}};
+  fe t[4];
+  for (int i = 0; i < 4; i++) { fe s; memcpy(&s, c[i], 32); fe_to_mont(&FQ, &t[i], &s); }
+  g->x.c0 = t[0]; g->x.c1 = t[1]; g->y.c0 = t[2]; g->y.c1 = t[3];
+}
+
+/* out[i] = scalars[i] * G (affine, Montgomery): 8-bit fixed-base windows, 32 tables of 255 points */
+#define DEFINE_FIXED(PFX, AFFSZ)                                                                           \
+  typedef struct { const uint64_t* sc; uint64_t lo, hi; const PFX##_aff* table; char* out; } PFX##_fjob;  \
+  static void* PFX##_fworker(void* arg) {                                                                  \
+    PFX##_fjob* j = (PFX##_fjob*)arg;                                                                      \
+    for (uint64_t i = j->lo; i < j->hi; i++) {                                                             \
+      PFX##_jac acc; PFX##_set_inf(&acc);                                                                  \
+      const uint8_t* kb = (const uint8_t*)(j->sc + 4 * i);                                                 \
+      for (int w = 0; w < 32; w++) if (kb[w]) PFX##_madd(&acc, &acc, &j->table[(size_t)w * 256 + kb[w]]);  \
+      PFX##_aff r; PFX##_to_aff(&r, &acc); memcpy(j->out + i * AFFSZ, &r, AFFSZ);                          \
+    }                                                                                                      \
+    return 0;                                                                                              \
+  }                                                                                                        \
+  int orc_fixed_base_##PFX(const void* scalars, uint64_t n, void* out, int nthreads) {                     \
+    PFX##_aff* table = (PFX##_aff*)calloc(32 * 256, sizeof(PFX##_aff));                                   \
+    PFX##_aff g; PFX##_gen(&g);                                                                            \
+    PFX##_jac base; PFX##_from_aff(&base, &g);                                                             \
+    for (int w = 0; w < 32; w++) {                                                                         \
+      PFX##_jac acc; PFX##_set_inf(&acc);                                                                  \
+      for (int d = 1; d < 256; d++) { PFX##_add(&acc, &acc, &base); PFX##_to_aff(&table[(size_t)w * 256 + d], &acc); } \
+      for (int k = 0; k < 8; k++) PFX##_dbl(&base, &base);                                                 \
+    }                                                                                                      \
+    if (nthreads < 1) nthreads = 1;                                                                        \
+    PFX##_fjob* jobs = (PFX##_fjob*)calloc((size_t)nthreads, sizeof(PFX##_fjob));                         \
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));                               \
+    for (int t = 0; t < nthreads; t++) {                                                                   \
+      jobs[t] = (PFX##_fjob){(const uint64_t*)scalars, n * t / nthreads, n * (t + 1) / nthreads, table, (char*)out}; \
+      if (t) pthread_create(&th[t], 0, PFX##_fworker, &jobs[t]);                                           \
+    }                                                                                                      \
+    PFX##_fworker(&jobs[0]);                                                                               \
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);                                             \
+    free(table); free(jobs); free(th);                                                                     \
+    return 0;                                                                                              \
+  }
+DEFINE_FIXED(g1, 64)
+DEFINE_FIXED(g2, 128)
+
+/* ---- NTT over Fr: iterative radix-2, natural order in and out (Fr.fft / Fr.ifft) ---------------- */
+static void fr_root(fe* w, unsigned k) {      /* w[k] = 5^((r-1)/2^28) squared 28-k times */
+  static const uint64_t e28[4] = {0x9b9709143e1f593full, 0x181585d2833e8487ull, 0x131a029b85045b68ull, 0x000000030644e72eull};
+  fe five; fe_from_u64(&FR, &five, 5); fe_pow(&FR, w, &five, e28);
+  for (unsigned i = 28; i > k; i--) fe_sqr(&FR, w, w);
+}
+int orc_ntt(void* data, unsigned k, int inverse) {
+  fe* a = (fe*)data; uint64_t n = 1ull << k;
+  for (uint64_t i = 1, j = 0; i < n; i++) {
+    uint64_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+  fe wn; fr_root(&wn, k);
+  if (inverse) fe_inv(&FR, &wn, &wn);
+  for (unsigned s = 1; s <= k; s++) {
+    uint64_t len = 1ull << s, half = len >> 1;
+    fe wl = wn;
+    for (unsigned i = s; i < k; i++) fe_sqr(&FR, &wl, &wl);
+    fe* tw = (fe*)malloc(half * sizeof(fe));
+    tw[0] = FR.one;
+    for (uint64_t t = 1; t < half; t++) fe_mul(&FR, &tw[t], &tw[t - 1], &wl);
+    for (uint64_t st = 0; st < n; st += len)
+      for (uint64_t t = 0; t < half; t++) {
+        fe u = a[st + t], v; fe_mul(&FR, &v, &a[st + t + half], &tw[t]);
+        fe_add(&FR, &a[st + t], &u, &v); fe_sub(&FR, &a[st + t + half], &u, &v);
+      }
+    free(tw);
+  }
+  if (inverse) {
+    fe ninv; fe_from_u64(&FR, &ninv, n); fe_inv(&FR, &ninv, &ninv);
+    for (uint64_t i = 0; i < n; i++) fe_mul(&FR, &a[i], &a[i], &ninv);
+  }
+  return 0;
+}
+
+/* ---- buildABC1 -> odd coset -> joinABC --------------------------------------------------------- */
+typedef struct __attribute__((packed)) { uint32_t m, c, s; uint8_t val[32]; } coef_rec;
+static void to_odd_coset(fe* a, unsigned k) {
+  uint64_t n = 1ull << k;
+  orc_ntt(a, k, 1);
+  fe inc, x = FR.one;
+  if (k == 28) fe_from_u64(&FR, &inc, 25); else fr_root(&inc, k + 1);
+  for (uint64_t j = 0; j < n; j++) { fe_mul(&FR, &a[j], &a[j], &x); fe_mul(&FR, &x, &x, &inc); }
+  orc_ntt(a, k, 0);
+}
+/* coeffs: payload of zkey section 4; witness: nvars x 32 B standard form; out: 2^k x 32 B standard form */
+int orc_h_scalars(const void* coeffs, uint64_t coeffs_size, const void* witness, uint64_t nvars, unsigned k, void* out) {
+  const uint8_t* cb = (const uint8_t*)coeffs;
+  uint32_t ncoef; memcpy(&ncoef, cb, 4);
+  if (coeffs_size != 4 + (uint64_t)ncoef * 44) return 1;
+  uint64_t n = 1ull << k;
+  fe* A = (fe*)calloc(3 * n, sizeof(fe)); fe* B = A + n; fe* C = B + n;
+  const coef_rec* recs = (const coef_rec*)(cb + 4);
+  const fe* w = (const fe*)witness;
+  for (uint32_t i = 0; i < ncoef; i++) {
+    coef_rec r; memcpy(&r, &recs[i], 44);
+    if (r.m > 1 || r.c >= n || r.s >= nvars) { free(A); return 2; }
+    fe v, p; memcpy(&v, r.val, 32);
+    fe_mul(&FR, &p, &v, &w[r.s]);
+    fe* dst = (r.m ? B : A) + r.c;
+    fe_add(&FR, dst, dst, &p);
+  }
+  for (uint64_t i = 0; i < n; i++) fe_mul(&FR, &C[i], &A[i], &B[i]);
+  to_odd_coset(A, k); to_odd_coset(B, k); to_odd_coset(C, k);
+  fe* o = (fe*)out;
+  for (uint64_t i = 0; i < n; i++) { fe t; fe_mul(&FR, &t, &A[i], &B[i]); fe_sub(&FR, &t, &t, &C[i]); fe_from_mont(&FR, &o[i], &t); }
+  free(A);
+  return 0;
+}
+
+/* ---- full prove (groth16_prove.js), container parsing included ------------------------------------ */
+typedef struct { const uint8_t* p; uint64_t len; } sect;
+static int find_sections(const uint8_t* buf, uint64_t size, const char* magic, sect* secs, int maxid) {
+  if (size < 12 || memcmp(buf, magic, 4)) return 1;
+  uint32_t nsec; memcpy(&nsec, buf + 8, 4);
+  uint64_t pos = 12;
+  for (int i = 0; i <= maxid; i++) { secs[i].p = 0; secs[i].len = 0; }
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > size) return 2;
+    uint32_t id; uint64_t len; memcpy(&id, buf + pos, 4); memcpy(&len, buf + pos + 4, 8); pos += 12;
+    if (len > size - pos) return 3;
+    if ((int)id <= maxid && !secs[id].p) { secs[id].p = buf + pos; secs[id].len = len; }
+    pos += len;
+  }
+  return 0;
+}
+/* r_le, s_le: 32-byte LE standard-form scalars. proof_points: pi_a(64) pi_b(128) pi_c(64), wire format.
+ * public_le: nPublic x 32 B. Returns 0 ok, 3 witness length mismatch, other = error. */
+int orc_prove(const void* zkey, uint64_t zkey_size, const void* wtns, uint64_t wtns_size, const uint8_t* r_le,
+              const uint8_t* s_le, uint8_t* proof_points, uint8_t* public_le, int nthreads) {
+  sect zs[11], ws[3];
+  if (find_sections((const uint8_t*)zkey, zkey_size, "zkey", zs, 10)) return 1;
+  if (find_sections((const uint8_t*)wtns, wtns_size, "wtns", ws, 2)) return 1;
+  for (int i = 1; i <= 9; i++) if (i != 3 && !zs[i].p) return 1;
+  if (!ws[1].p || !ws[2].p) return 1;
+  const uint8_t* h = zs[2].p;
+  uint32_t nvars, npub, domain; memcpy(&nvars, h + 72, 4); memcpy(&npub, h + 76, 4); memcpy(&domain, h + 80, 4);
+  if (memcmp(ws[1].p + 4, RP, 32)) return 4;
+  uint32_t nwit; memcpy(&nwit, ws[1].p + 36, 4);
+  if (nwit != nvars) return 3;
+  unsigned k = 0; while ((1u << k) < domain) k++;
+  const uint8_t* hp = h + 84;
+  g1_aff alpha1, beta1, delta1; g2_aff beta2, delta2;
+  memcpy(&alpha1, hp, 64); memcpy(&beta1, hp + 64, 64); memcpy(&beta2, hp + 128, 128);
+  memcpy(&delta1, hp + 384, 64); memcpy(&delta2, hp + 448, 128);
+  const uint8_t* w = ws[2].p;
+  fe* P = (fe*)malloc((size_t)domain * 32);
+  if (orc_h_scalars(zs[4].p, zs[4].len, w, nvars, k, P)) { free(P); return 5; }
+  g1_aff A, B1, C, H; g2_aff B2;
+  orc_msm_g1(zs[5].p, w, nvars, &A, nthreads);
+  orc_msm_g1(zs[6].p, w, nvars, &B1, nthreads);
+  orc_msm_g2(zs[7].p, w, nvars, &B2, nthreads);
+  orc_msm_g1(zs[8].p, w + 32 * (size_t)(npub + 1), nvars - npub - 1, &C, nthreads);
+  orc_msm_g1(zs[9].p, P, domain, &H, nthreads);
+  free(P);
+  uint64_t rk[4], sk[4], nrs[4]; memcpy(rk, r_le, 32); memcpy(sk, s_le, 32);
+  fe rm, sm, rs; fe t; memcpy(&t, r_le, 32); fe_to_mont(&FR, &rm, &t); memcpy(&t, s_le, 32); fe_to_mont(&FR, &sm, &t);
+  fe_mul(&FR, &rs, &rm, &sm); fe_neg(&FR, &rs, &rs); fe_from_mont(&FR, &t, &rs); memcpy(nrs, &t, 32);
+  g1_jac pa, pb1, pc, d1, tmp; g2_jac pb, d2, tmp2;
+  g1_from_aff(&d1, &delta1); g2_from_aff(&d2, &delta2);
+  g1_from_aff(&pa, &A); g1_madd(&pa, &pa, &alpha1); g1_mul(&tmp, &d1, rk); g1_add(&pa, &pa, &tmp);
+  g2_from_aff(&pb, &B2); g2_madd(&pb, &pb, &beta2); g2_mul(&tmp2, &d2, sk); g2_add(&pb, &pb, &tmp2);
+  g1_from_aff(&pb1, &B1); g1_madd(&pb1, &pb1, &beta1); g1_mul(&tmp, &d1, sk); g1_add(&pb1, &pb1, &tmp);
+  g1_from_aff(&pc, &C); g1_madd(&pc, &pc, &H);
+  g1_mul(&tmp, &pa, sk); g1_add(&pc, &pc, &tmp);
+  g1_mul(&tmp, &pb1, rk); g1_add(&pc, &pc, &tmp);
+  g1_mul(&tmp, &d1, nrs); g1_add(&pc, &pc, &tmp);
+  g1_aff oa, oc; g2_aff ob;
+  g1_to_aff(&oa, &pa); g2_to_aff(&ob, &pb); g1_to_aff(&oc, &pc);
+  memcpy(proof_points, &oa, 64); memcpy(proof_points + 64, &ob, 128); memcpy(proof_points + 192, &oc, 64);
+  memcpy(public_le, w + 32, (size_t)npub * 32);
+  return 0;
+}
+
+/* ---- element-wise exports used by the oracle-vs-oracle tests ------------------------------------ */
+/* field 0 = Fq, 1 = Fr; op 0 = Montgomery mul, 1 = add, 2 = sub, 3 = inverse, 4 = to Montgomery, 5 = from */
+int orc_field_op(int fld, int op, const void* a, const void* b, void* out, uint64_t n) {
+  const field* F = fld ? &FR : &FQ;
+  const fe* x = (const fe*)a; const fe* y = (const fe*)b; fe* o = (fe*)out;
+  for (uint64_t i = 0; i < n; i++) {
+    switch (op) {
+      case 0: fe_mul(F, &o[i], &x[i], &y[i]); break;
+      case 1: fe_add(F, &o[i], &x[i], &y[i]); break;
+      case 2: fe_sub(F, &o[i], &x[i], &y[i]); break;
+      case 3: fe_inv(F, &o[i], &x[i]); break;
+      case 4: fe_to_mont(F, &o[i], &x[i]); break;
+      default: fe_from_mont(F, &o[i], &x[i]); break;
+    }
+  }
+  return 0;
+}
+int orc_group_add(int group, const void* a, const void* b, void* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) {
+    if (group == 1) {
+      g1_jac p; g1_aff r; g1_from_aff(&p, (const g1_aff*)a + i); g1_madd(&p, &p, (const g1_aff*)b + i);
+      g1_to_aff(&r, &p); memcpy((char*)out + 64 * i, &r, 64);
+    } else {
+      g2_jac p; g2_aff r; g2_from_aff(&p, (const g2_aff*)a + i); g2_madd(&p, &p, (const g2_aff*)b + i);
+      g2_to_aff(&r, &p); memcpy((char*)out + 128 * i, &r, 128);
+    }
+  }
+  return 0;
+}

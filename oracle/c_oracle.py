@@ -1,0 +1,109 @@
+"""ORACLE (test infrastructure) -- ctypes loader for oracle/_build/liboracle.so (oracle/c/zkpoa_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")])
+        L = ctypes.CDLL(_SO)
+        vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+        L.orc_msm_g1.argtypes = [vp, vp, u64, vp, ci]
+        L.orc_msm_g2.argtypes = [vp, vp, u64, vp, ci]
+        L.orc_fixed_base_g1.argtypes = [vp, u64, vp, ci]
+        L.orc_fixed_base_g2.argtypes = [vp, u64, vp, ci]
+        L.orc_ntt.argtypes = [vp, ctypes.c_uint, ci]
+        L.orc_h_scalars.argtypes = [vp, u64, vp, u64, ctypes.c_uint, vp]
+        L.orc_prove.argtypes = [vp, u64, vp, u64, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ci]
+        L.orc_field_op.argtypes = [ci, ci, vp, vp, vp, u64]
+        L.orc_group_add.argtypes = [ci, vp, vp, vp, u64]
+        _lib = L
+    return _lib
+
+
+def _in(b):
+    return ctypes.cast(ctypes.create_string_buffer(bytes(b), len(b)), ctypes.c_void_p) if not isinstance(b, ctypes.Array) else b
+
+
+def msm_g1(bases, scalars, n=None, nthreads=1):
+    n = len(scalars) // 32 if n is None else n
+    out = ctypes.create_string_buffer(64)
+    lib().orc_msm_g1(bytes(bases), bytes(scalars), n, out, nthreads)
+    return out.raw
+
+
+def msm_g2(bases, scalars, n=None, nthreads=1):
+    n = len(scalars) // 32 if n is None else n
+    out = ctypes.create_string_buffer(128)
+    lib().orc_msm_g2(bytes(bases), bytes(scalars), n, out, nthreads)
+    return out.raw
+
+
+def fixed_base_g1(scalars, nthreads=1):
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(max(1, 64 * n))
+    lib().orc_fixed_base_g1(bytes(scalars), n, out, nthreads)
+    return out.raw[:64 * n]
+
+
+def fixed_base_g2(scalars, nthreads=1):
+    n = len(scalars) // 32
+    out = ctypes.create_string_buffer(max(1, 128 * n))
+    lib().orc_fixed_base_g2(bytes(scalars), n, out, nthreads)
+    return out.raw[:128 * n]
+
+
+def ntt(data, k, inverse=False):
+    buf = ctypes.create_string_buffer(bytes(data), 32 << k)
+    lib().orc_ntt(buf, k, 1 if inverse else 0)
+    return buf.raw
+
+
+def h_scalars(coeffs_section, witness, n_vars, k):
+    out = ctypes.create_string_buffer(32 << k)
+    rc = lib().orc_h_scalars(bytes(coeffs_section), len(coeffs_section), bytes(witness), n_vars, k, out)
+    if rc:
+        raise ValueError("orc_h_scalars rc=%d" % rc)
+    return out.raw
+
+
+def prove(zkey, wtns, r=0, s=0, nthreads=1, n_public=None):
+    """-> (proof_points[256], public bytes) ; raises on error (rc 3 = witness length mismatch)."""
+    pts = ctypes.create_string_buffer(256)
+    pub = ctypes.create_string_buffer(1 << 16)
+    rc = lib().orc_prove(bytes(zkey), len(zkey), bytes(wtns), len(wtns), int(r).to_bytes(32, "little"),
+                         int(s).to_bytes(32, "little"), pts, pub, nthreads)
+    if rc:
+        raise ValueError("orc_prove rc=%d" % rc)
+    if n_public is None:
+        import struct
+        # header: section 2 of the zkey; locate nPublic
+        from .py import groth16 as g16
+        secs = g16.read_binfile(zkey, "zkey", 2)
+        p, _ = secs[2][0]
+        n_public = struct.unpack_from("<I", zkey, p + 76)[0]
+    return pts.raw, pub.raw[:32 * n_public]
+
+
+def field_op(field, op, a, b=None):
+    n = len(a) // 32
+    out = ctypes.create_string_buffer(max(1, 32 * n))
+    lib().orc_field_op(field, op, bytes(a), bytes(b) if b is not None else bytes(a), out, n)
+    return out.raw[:32 * n]
+
+
+def group_add(group, a, b):
+    size = 64 if group == 1 else 128
+    n = len(a) // size
+    out = ctypes.create_string_buffer(max(1, size * n))
+    lib().orc_group_add(group, bytes(a), bytes(b), out, n)
+    return out.raw[:size * n]

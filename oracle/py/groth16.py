@@ -162,17 +162,19 @@ def fr_lagrange_at(tau, n):
     return out
 
 
-def synthetic_setup(nVars, nPublic, constraints, toxic, g1mul=None, g2mul=None):
+def synthetic_setup(nVars, nPublic, constraints, toxic, g1_batch=None, g2_batch=None):
     """Build a real-format .zkey for an R1CS from known toxic waste.
 
     constraints: list of (lcA, lcB, lcC), each lc a dict {signal: coef}.
     toxic: dict tau, alpha, beta, gamma, delta (ints mod r).
+    g1_batch / g2_batch: optional callables [scalars] -> concatenated wire-format bytes of k*G
+    (e.g. the C oracle's fixed-base routine, for circuits too large for Python scalar muls).
     Returns (zkey_bytes, vkey_dict). Mirrors snarkjs `zkey new` output conventions
     (SURVEY.md 8c): nPublic+1 extra A rows, coefficient values scaled by R^2, H = odd
     points of the size-2n Lagrange basis divided by delta.
     """
-    g1mul = g1mul or (lambda k: bn.g1_mul(bn.G1_GEN, k))
-    g2mul = g2mul or (lambda k: bn.g2_mul(bn.G2_GEN, k))
+    g1_batch = g1_batch or (lambda ks: b"".join(g1_to_bytes(bn.g1_mul(bn.G1_GEN, k)) for k in ks))
+    g2_batch = g2_batch or (lambda ks: b"".join(g2_to_bytes(bn.g2_mul(bn.G2_GEN, k)) for k in ks))
     tau, alpha, beta, gamma, delta = (toxic[k] % R for k in ("tau", "alpha", "beta", "gamma", "delta"))
     ncons = len(constraints)
     n = 1
@@ -200,28 +202,30 @@ def synthetic_setup(nVars, nPublic, constraints, toxic, g1mul=None, g2mul=None):
     L2 = fr_lagrange_at(tau, 2 * n)
     r2 = MONT_R * MONT_R % R
 
+    K = [(beta * At[i] + alpha * Bt[i] + Ct[i]) % R for i in range(nVars)]
+    hdr1 = g1_batch([alpha, beta, delta])
+    hdr2 = g2_batch([beta, gamma, delta])
+    alpha1_b, beta1_b, delta1_b = hdr1[0:64], hdr1[64:128], hdr1[128:192]
+    beta2_b, gamma2_b, delta2_b = hdr2[0:128], hdr2[128:256], hdr2[256:384]
     sec2 = struct.pack("<I", 32) + _le32(Q) + struct.pack("<I", 32) + _le32(R)
     sec2 += struct.pack("<III", nVars, nPublic, n)
-    alpha1, beta1, beta2 = g1mul(alpha), g1mul(beta), g2mul(beta)
-    gamma2, delta1, delta2 = g2mul(gamma), g1mul(delta), g2mul(delta)
-    sec2 += g1_to_bytes(alpha1) + g1_to_bytes(beta1) + g2_to_bytes(beta2)
-    sec2 += g2_to_bytes(gamma2) + g1_to_bytes(delta1) + g2_to_bytes(delta2)
-    K = [(beta * At[i] + alpha * Bt[i] + Ct[i]) % R for i in range(nVars)]
-    IC = [g1mul(K[i] * ginv % R) for i in range(nPublic + 1)]
-    sec3 = b"".join(g1_to_bytes(P) for P in IC)
+    sec2 += alpha1_b + beta1_b + beta2_b + gamma2_b + delta1_b + delta2_b
+    sec3 = g1_batch([K[i] * ginv % R for i in range(nPublic + 1)])
     sec4 = struct.pack("<I", len(coefs)) + b"".join(
         struct.pack("<III", m, c, s) + _le32(v * r2 % R) for (m, c, s, v) in coefs)
-    sec5 = b"".join(g1_to_bytes(g1mul(At[i])) for i in range(nVars))
-    sec6 = b"".join(g1_to_bytes(g1mul(Bt[i])) for i in range(nVars))
-    sec7 = b"".join(g2_to_bytes(g2mul(Bt[i])) for i in range(nVars))
-    sec8 = b"".join(g1_to_bytes(g1mul(K[i] * dinv % R)) for i in range(nPublic + 1, nVars))
-    sec9 = b"".join(g1_to_bytes(g1mul(L2[2 * i + 1] * dinv % R)) for i in range(n))
+    sec5 = g1_batch(At)
+    sec6 = g1_batch(Bt)
+    sec7 = g2_batch(Bt)
+    sec8 = g1_batch([K[i] * dinv % R for i in range(nPublic + 1, nVars)])
+    sec9 = g1_batch([L2[2 * i + 1] * dinv % R for i in range(n)])
     sec10 = bytes(64) + struct.pack("<I", 0)
     zkey = write_binfile("zkey", 1, [(1, struct.pack("<I", 1)), (2, sec2), (3, sec3), (4, sec4), (5, sec5),
                                      (6, sec6), (7, sec7), (8, sec8), (9, sec9), (10, sec10)])
+    IC = [g1_from_bytes(sec3, 64 * i) for i in range(nPublic + 1)]
     vkey = {"protocol": "groth16", "curve": "bn128", "nPublic": nPublic,
-            "vk_alpha_1": g1_to_obj(alpha1), "vk_beta_2": g2_to_obj(beta2), "vk_gamma_2": g2_to_obj(gamma2),
-            "vk_delta_2": g2_to_obj(delta2), "IC": [g1_to_obj(P) for P in IC]}
+            "vk_alpha_1": g1_to_obj(g1_from_bytes(alpha1_b)), "vk_beta_2": g2_to_obj(g2_from_bytes(beta2_b)),
+            "vk_gamma_2": g2_to_obj(g2_from_bytes(gamma2_b)), "vk_delta_2": g2_to_obj(g2_from_bytes(delta2_b)),
+            "IC": [g1_to_obj(P) for P in IC]}
     return zkey, vkey
 
 
