@@ -1,0 +1,114 @@
+"""The C-ABI boundary without a GPU: libzkpoa_prover.so loads, exports every symbol that
+include/zkpoa_prover.h declares, host-only entry points work, and anything that needs the GPU
+fails loudly instead of falling back to the CPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, golden_case
+from oracle.py import bn254 as bn
+from oracle.py import groth16 as g16
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zkpoa_prover.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b((?:zkpoa|groth16)_\w+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_all_exported(zk):
+    L = zk.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert missing == []
+    assert sorted(zk.EXPORTS) == declared
+
+
+def test_host_only_group_helpers(zk):
+    G = g16.g1_to_bytes(bn.G1_GEN)
+    assert g16.g1_from_bytes(zk.g1_mul(G, 123456789)) == bn.g1_mul(bn.G1_GEN, 123456789)
+    G2 = g16.g2_to_bytes(bn.G2_GEN)
+    assert g16.g2_from_bytes(zk.g2_mul(G2, bn.R - 5)) == bn.g2_mul(bn.G2_GEN, bn.R - 5)
+    pts = [bn.g1_mul(bn.G1_GEN, k) for k in (3, 5, 7)] + [None]
+    assert g16.g1_from_bytes(zk.g1_sum(b"".join(g16.g1_to_bytes(p) for p in pts))) == bn.g1_mul(bn.G1_GEN, 15)
+    # P + (-P) and doubling through the sum path
+    P = bn.g1_mul(bn.G1_GEN, 99)
+    assert g16.g1_from_bytes(zk.g1_sum(g16.g1_to_bytes(P) + g16.g1_to_bytes(bn.ec_neg(P, bn.FQ)))) is None
+    assert g16.g1_from_bytes(zk.g1_sum(g16.g1_to_bytes(P) * 2)) == bn.g1_mul(bn.G1_GEN, 198)
+    pts2 = [bn.g2_mul(bn.G2_GEN, k) for k in (2, 9)]
+    assert g16.g2_from_bytes(zk.g2_sum(b"".join(g16.g2_to_bytes(p) for p in pts2))) == bn.g2_mul(bn.G2_GEN, 11)
+
+
+@pytest.mark.parametrize("tag", ["n8", "n128"])
+def test_json_writers_match_reference_formats(zk, tag):
+    """zkpoa_proof_to_json / zkpoa_public_to_json (host-only) reproduce the golden JSON bytes, which
+    follow the reference's committed rapidsnark- and snarkjs-style files."""
+    import json
+    g = golden_case(tag)
+    obj = json.loads(g["proof_rapidsnark.json"])
+    pts = (g16.g1_to_bytes(g16.g1_from_obj(obj["pi_a"])) + g16.g2_to_bytes(g16.g2_from_obj(obj["pi_b"])) +
+           g16.g1_to_bytes(g16.g1_from_obj(obj["pi_c"])))
+    pub = b"".join(int(v).to_bytes(32, "little") for v in json.loads(g["public_rapidsnark.json"]))
+    assert zk.proof_to_json(pts, "rapidsnark") == g["proof_rapidsnark.json"]
+    assert zk.proof_to_json(pts, "snarkjs") == g["proof_snarkjs.json"]
+    assert zk.public_to_json(pub, "rapidsnark") == g["public_rapidsnark.json"]
+    assert zk.public_to_json(pub, "snarkjs") == g["public_snarkjs.json"]
+
+
+def test_json_writer_on_reference_fixture(zk):
+    """Round-trip one of the reference's own proof.json files through the product's writer."""
+    import json
+    d = os.path.join(ROOT, "tests", "golden", "ref", "4_sigs_2_batches_12_height__layer_three")
+    raw = open(os.path.join(d, "proof.json")).read()
+    obj = json.loads(raw)
+    pts = (g16.g1_to_bytes(g16.g1_from_obj(obj["pi_a"])) + g16.g2_to_bytes(g16.g2_from_obj(obj["pi_b"])) +
+           g16.g1_to_bytes(g16.g1_from_obj(obj["pi_c"])))
+    assert zk.proof_to_json(pts, "rapidsnark") == raw
+    rawp = open(os.path.join(d, "public.json")).read()
+    pub = b"".join(int(v).to_bytes(32, "little") for v in json.loads(rawp))
+    assert zk.public_to_json(pub, "rapidsnark") == rawp
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_fails_loudly(zk, tmp_path):
+    with pytest.raises(zk.ZkpoaError):
+        zk.Context(0)
+    g = golden_case("n8")
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "w.wtns").write_bytes(g["witness.wtns"])
+    with pytest.raises(zk.ZkpoaError):
+        zk.groth16_prove(str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns"), str(tmp_path / "p.json"),
+                         str(tmp_path / "u.json"))
+    rc = subprocess.run([zk.PROVER_BIN, str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns"),
+                         str(tmp_path / "p.json"), str(tmp_path / "u.json")], capture_output=True, text=True)
+    assert rc.returncode != 0 and "Error" in rc.stderr
+    assert not (tmp_path / "p.json").exists()
+
+
+def test_cli_usage_error(zk):
+    rc = subprocess.run([zk.PROVER_BIN, "only-one-arg"], capture_output=True, text=True)
+    assert rc.returncode != 0 and "Usage" in rc.stderr
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must not import, link or execute anything under oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "zk-proof-of-assets_amd")):
+        if os.sep + "build" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"oracle[/.]|liboracle|c_oracle|import oracle|from oracle", text):
+                    bad.append(os.path.join(base, f))
+    assert bad == []

@@ -1,0 +1,247 @@
+"""GPU parity tests for the kernels of the path, through the C ABI (libzkpoa_prover.so), against
+the oracle (golden vectors from the Python big-int oracle; the C restatement at sizes it finishes in
+seconds; size-independent properties at BASELINE.json's full size 2^20).
+Bar: bit-exact (integer arithmetic)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import le, rd
+from oracle import c_oracle as co
+from oracle.py import bn254 as bn
+from oracle.py import groth16 as g16
+
+pytestmark = pytest.mark.gpu
+Q, R, M = bn.Q, bn.R, bn.MONT_R
+
+
+def _cat(hexes):
+    return b"".join(bytes.fromhex(h) for h in hexes)
+
+
+# ---- field layer ---------------------------------------------------------------
+@pytest.mark.parametrize("name,field", [("fq", 0), ("fr", 1)])
+def test_field_golden(ctx, vectors, name, field):
+    v = vectors[name]
+    a, b = _cat(v["a"]), _cat(v["b"])
+    assert ctx.field_op(field, 0, a, b) == _cat(v["mont_mul"])
+    assert ctx.field_op(field, 1, a, b) == _cat(v["add"])
+    assert ctx.field_op(field, 2, a, b) == _cat(v["sub"])
+    assert ctx.field_op(field, 3, a) == _cat(v["mont_inv"])
+    assert ctx.field_op(field, 4, a) == _cat(v["to_mont"])
+    assert ctx.field_op(field, 5, a) == _cat(v["from_mont"])
+
+
+@pytest.mark.parametrize("field,p", [(0, Q), (1, R)])
+def test_field_random_vs_c_oracle(ctx, field, p):
+    rng = np.random.default_rng(field + 5)
+    n = 50000
+    limbs = rng.integers(0, 1 << 63, size=(2, n, 4), dtype=np.uint64) * 2 + 1
+    limbs[:, :, 3] &= np.uint64((1 << 60) - 1)
+    a, b = limbs[0].tobytes(), limbs[1].tobytes()
+    for op in (0, 1, 2):
+        assert ctx.field_op(field, op, a, b) == co.field_op(field, op, a, b)
+    assert ctx.field_op(field, 0, b"", b"") == b""          # empty input
+
+
+# ---- group layer -----------------------------------------------------------------------------------
+def test_group_add_golden(ctx, vectors):
+    for key, grp in (("g1_add", 1), ("g2_add", 2)):
+        v = vectors[key]
+        assert ctx.group_add(grp, _cat(v["a"]), _cat(v["b"])) == _cat(v["sum"])
+
+
+# ---- MSM ---------------------------------------------------------------------
+def test_msm_golden(ctx, vectors):
+    for m in vectors["msm"]:
+        fn = ctx.msm_g1 if m["group"] == 1 else ctx.msm_g2
+        assert fn(bytes.fromhex(m["bases"]), bytes.fromhex(m["scalars"]), m["n"]).hex() == m["result"]
+
+
+def test_msm_empty(ctx):
+    assert ctx.msm_g1(b"", b"", 0) == bytes(64)
+    assert ctx.msm_g2(b"", b"", 0) == bytes(128)
+
+
+def _rand_scalars(rng, n, dist):
+    special = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, 1 << 16, (1 << 16) - 1, 1 << 15]
+    out = []
+    for _ in range(n):
+        u = rng.random()
+        if dist == "witness":
+            out.append(rng.randrange(2) if u < 0.55 else rng.randrange(1 << 64) if u < 0.9 else rng.randrange(R))
+        elif dist == "special":
+            out.append(rng.choice(special))
+        else:
+            out.append(rng.randrange(R))
+    return b"".join(le(k) for k in out)
+
+
+@pytest.mark.parametrize("n,dist", [(3000, "uniform"), (3000, "witness"), (500, "special"), (20000, "witness")])
+def test_msm_g1_vs_c_oracle(ctx, n, dist):
+    rng = random.Random(n + len(dist))
+    bases = bytearray(co.fixed_base_g1(b"".join(le(rng.randrange(R)) for _ in range(n)), 8))
+    for i in range(0, n, 17):                      # infinity bases, as unused wires have in a zkey
+        bases[64 * i:64 * i + 64] = bytes(64)
+    sc = _rand_scalars(rng, n, dist)
+    assert ctx.msm_g1(bytes(bases), sc, n) == co.msm_g1(bytes(bases), sc, n, 8)
+
+
+@pytest.mark.parametrize("n,dist", [(700, "uniform"), (2000, "witness")])
+def test_msm_g2_vs_c_oracle(ctx, n, dist):
+    rng = random.Random(n)
+    bases = bytearray(co.fixed_base_g2(b"".join(le(rng.randrange(R)) for _ in range(n)), 8))
+    for i in range(0, n, 13):
+        bases[128 * i:128 * i + 128] = bytes(128)
+    sc = _rand_scalars(rng, n, dist)
+    assert ctx.msm_g2(bytes(bases), sc, n) == co.msm_g2(bytes(bases), sc, n, 8)
+
+
+def test_msm_repeated_and_opposite_bases(ctx):
+    """All bases equal (bucket accumulation hits the doubling case) and P / -P pairs (hits P + (-P))."""
+    n = 512
+    G = g16.g1_to_bytes(bn.G1_GEN)
+    negG = g16.g1_to_bytes(bn.ec_neg(bn.G1_GEN, bn.FQ))
+    sc = le(5) * n
+    assert g16.g1_from_bytes(ctx.msm_g1(G * n, sc, n)) == bn.g1_mul(bn.G1_GEN, 5 * n)
+    bases = (G + negG) * (n // 2)
+    assert ctx.msm_g1(bases, sc, n) == bytes(64)
+    sc2 = b"".join(le(7 if i % 2 == 0 else 3) for i in range(n))
+    assert g16.g1_from_bytes(ctx.msm_g1(bases, sc2, n)) == bn.g1_mul(bn.G1_GEN, 4 * (n // 2))
+
+
+@pytest.mark.parametrize("c", [4, 8, 11, 14, 20])
+def test_msm_forced_windows(ctx, c):
+    rng = random.Random(c)
+    n = 4096
+    bases = co.fixed_base_g1(b"".join(le(rng.randrange(R)) for _ in range(n)), 8)
+    sc = _rand_scalars(rng, n, "witness")
+    ctx.set_option("msm_c", c)
+    try:
+        got = ctx.msm_g1(bases, sc, n)
+    finally:
+        ctx.set_option("msm_c", 0)
+    assert got == co.msm_g1(bases, sc, n, 8)
+
+
+def _dlog_setup(ctx, n, seed, group=1):
+    import torch
+    rng = random.Random(seed)
+    a, b = rng.randrange(R), rng.randrange(R)
+    size = 64 if group == 1 else 128
+    d_bases = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+    (ctx.gen_bases_g1_device if group == 1 else ctx.gen_bases_g2_device)(a, b, 0, n, d_bases.data_ptr())
+    return a, b, d_bases
+
+
+def _np_scalars(n, seed, dist="uniform"):
+    nr = np.random.default_rng(seed)
+    limbs = nr.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + nr.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] &= np.uint64((1 << 60) - 1)
+    if dist == "witness":
+        u = nr.random(n)
+        small = u < 0.55
+        limbs[small, 1:] = 0
+        limbs[small, 0] = nr.integers(0, 2, size=int(small.sum()), dtype=np.uint64)
+        limbs[(u >= 0.55) & (u < 0.9), 1:] = 0
+    return limbs
+
+
+def _dlog_expected(limbs, a, b):
+    """(sum k_i (a + i b)) mod r from the limb columns, O(n) integer work."""
+    n = limbs.shape[0]
+    idx = np.arange(n, dtype=object)
+    s0 = s1 = 0
+    for j in range(4):
+        col = limbs[:, j].astype(object)
+        s0 += int(col.sum()) << (64 * j)
+        s1 += int((col * idx).sum()) << (64 * j)
+    return (a * s0 + b * s1) % R
+
+
+@pytest.mark.parametrize("dist", ["uniform", "witness"])
+def test_msm_g1_full_size_known_dlog(ctx, dist):
+    """BASELINE.json configs[1]: 2^20 points. Bases (a + i b) G are generated on the device; the
+    expected result is a field-only O(n) computation."""
+    import torch
+    n = 1 << 20
+    a, b, d_bases = _dlog_setup(ctx, n, 99)
+    hb = bytes(d_bases[:128].cpu().numpy())
+    assert g16.g1_from_bytes(hb, 0) == bn.g1_mul(bn.G1_GEN, a)
+    assert g16.g1_from_bytes(hb, 64) == bn.g1_mul(bn.G1_GEN, (a + b) % R)
+    limbs = _np_scalars(n, 7, dist)
+    d_sc = torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).cuda()
+    out = ctx.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)
+    assert g16.g1_from_bytes(out) == bn.g1_mul(bn.G1_GEN, _dlog_expected(limbs, a, b))
+
+
+def test_msm_linearity_full_size(ctx, zk):
+    """MSM(k) + MSM(k') == MSM(k + k') at 2^20 (k + k' < r by construction)."""
+    import torch
+    n = 1 << 20
+    _, _, d_bases = _dlog_setup(ctx, n, 5)
+    k1 = _np_scalars(n, 1)
+    k2 = _np_scalars(n, 2, "witness")
+    k1[:, 3] >>= np.uint64(1)
+    k2[:, 3] >>= np.uint64(1)
+    ks = np.zeros_like(k1)
+    carry = np.zeros(n, dtype=np.uint64)
+    for j in range(4):
+        s = k1[:, j] + k2[:, j]
+        c1 = s < k1[:, j]
+        s2 = s + carry
+        c2 = s2 < s
+        ks[:, j] = s2
+        carry = (c1 | c2).astype(np.uint64)
+    outs = []
+    for arr in (k1, k2, ks):
+        d = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).cuda()
+        outs.append(ctx.msm_g1_device(d_bases.data_ptr(), d.data_ptr(), n))
+    assert zk.g1_sum(outs[0] + outs[1]) == outs[2]
+
+
+def test_msm_g2_known_dlog(ctx):
+    import torch
+    n = 1 << 16
+    a, b, d_bases = _dlog_setup(ctx, n, 123, group=2)
+    limbs = _np_scalars(n, 3, "witness")
+    d_sc = torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).cuda()
+    out = ctx.msm_g2_device(d_bases.data_ptr(), d_sc.data_ptr(), n)
+    assert g16.g2_from_bytes(out) == bn.g2_mul(bn.G2_GEN, _dlog_expected(limbs, a, b))
+
+
+# ---- NTT ----------------------------------------------------------------------------
+def test_ntt_golden(ctx, vectors):
+    for t in vectors["ntt"]:
+        assert ctx.ntt(bytes.fromhex(t["in"]), t["k"]).hex() == t["fwd"]
+        assert ctx.ntt(bytes.fromhex(t["in"]), t["k"], inverse=True).hex() == t["inv"]
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 7, 10, 11, 12, 13, 15, 17])
+def test_ntt_vs_c_oracle(ctx, k):
+    """Covers the single-pass (k <= 11), two-pass (12..19) plans of the LDS transform."""
+    nr = np.random.default_rng(k)
+    limbs = nr.integers(0, 1 << 62, size=(1 << k, 4), dtype=np.uint64)
+    limbs[:, 3] &= np.uint64((1 << 59) - 1)
+    x = limbs.tobytes()
+    assert ctx.ntt(x, k) == co.ntt(x, k)
+    assert ctx.ntt(x, k, inverse=True) == co.ntt(x, k, inverse=True)
+
+
+def test_ntt_roundtrip_and_linearity_large(ctx):
+    """2^22 (three passes): ifft(fft(x)) == x and fft(x + y) == fft(x) + fft(y)."""
+    k = 22
+    nr = np.random.default_rng(0)
+    xs = []
+    for _ in range(2):
+        limbs = nr.integers(0, 1 << 62, size=(1 << k, 4), dtype=np.uint64)
+        limbs[:, 3] &= np.uint64((1 << 58) - 1)
+        xs.append(limbs)
+    x, y = xs[0].tobytes(), xs[1].tobytes()
+    fx = ctx.ntt(x, k)
+    assert ctx.ntt(fx, k, inverse=True) == x
+    fy = ctx.ntt(y, k)
+    s = (xs[0].astype(object) + 0)  # limb-wise sum without carries is not a field sum: use the device add
+    xy = ctx.field_op(1, 1, x, y)
+    assert ctx.ntt(xy, k) == ctx.field_op(1, 1, fx, fy)
