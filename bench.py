@@ -158,17 +158,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle as co
             cores = os.cpu_count() or 1
-            sample_log = min(logn, 18)
+            sample_log = min(logn, 20)      # ~10-20 s of CPU work spread over the host cores
             ns = 1 << sample_log
             hb = bytes(d_bases[:ns * 64].cpu().numpy())
             hs = limbs[:ns].tobytes()
             tc = time.perf_counter()
-            ref = co.msm_g1(hb, hs, ns, cores)
+            windows = co.msm_windows(ns)     # the C oracle threads by window: threads used = min(cores, windows)
+            threads = min(cores, windows)
+            ref = co.msm_g1(hb, hs, ns, threads)
             tcpu = time.perf_counter() - tc
             chk = ctx.msm_g1_device(d_bases.data_ptr(), d_scalars.data_ptr(), ns)
             if chk != ref:
                 raise SystemExit("bench.py: GPU and CPU-oracle MSM disagree on the baseline sample")
-            line["cpu_baseline"] = {"value": ns / tcpu, "unit": "pts/s", "cores": min(cores, 22), "kind": "port",
+            line["cpu_baseline"] = {"value": ns / tcpu, "unit": "pts/s", "cores": threads, "kind": "port",
                                     "sample": "first 2^%d points of the same workload, one MSM, C oracle "
                                               "(oracle/c, Pippenger threaded by window)" % sample_log,
                                     "seconds": tcpu}

@@ -34,6 +34,16 @@ def _in(b):
     return ctypes.cast(ctypes.create_string_buffer(bytes(b), len(b)), ctypes.c_void_p) if not isinstance(b, ctypes.Array) else b
 
 
+def msm_windows(n):
+    """Number of Pippenger windows the C oracle uses for n points (= its maximum useful thread count)."""
+    best, bc = 1, None
+    for c in range(1, 17):
+        cost = ((254 + c - 1) // c) * (n + 2.0 * (1 << c))
+        if bc is None or cost < bc:
+            best, bc = c, cost
+    return (254 + best - 1) // best
+
+
 def msm_g1(bases, scalars, n=None, nthreads=1):
     n = len(scalars) // 32 if n is None else n
     out = ctypes.create_string_buffer(64)
