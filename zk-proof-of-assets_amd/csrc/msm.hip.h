@@ -290,19 +290,96 @@ ZK_DEV uint32_t find_bucket(const uint32_t* __restrict__ po, uint32_t nb, uint32
   return lo;
 }
 
+// ---- 4a: order the pieces by length, longest first ----------------------------------------------
+// Piece lengths follow the bucket-count distribution (Poisson for uniform scalars), so lanes of one
+// wave would idle behind its longest piece and the last workgroups of the grid would run alone.
+// A counting sort of piece ids by length (<= K0 distinct keys; LDS histogram per workgroup, one
+// global atomic per (workgroup, length)) gives every wave equal-length pieces and schedules the
+// longest first.
+constexpr uint32_t kMaxPieceLen = 512;
+
+// pass 1: piece t -> (bucket, length); histogram of lengths
+static __global__ __launch_bounds__(256) void msm_piece_len_kernel(const uint32_t* __restrict__ cnt0,
+                                                                   const uint32_t* __restrict__ po1, uint32_t TB,
+                                                                   uint32_t K0, uint32_t* __restrict__ pbkt,
+                                                                   uint32_t* __restrict__ plen,
+                                                                   uint32_t* __restrict__ len_hist) {
+  __shared__ uint32_t h[kMaxPieceLen + 1];
+  for (uint32_t i = threadIdx.x; i <= kMaxPieceLen; i += 256u) h[i] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  uint32_t total = po1[TB];
+  if (t < total) {
+    uint32_t b = find_bucket(po1, TB, t);
+    uint32_t j = t - po1[b];
+    uint32_t len = cnt0[b] - j * K0;
+    if (len > K0) len = K0;
+    pbkt[t] = b;
+    plen[t] = len;
+    atomicAdd(&h[len], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= kMaxPieceLen; i += 256u)
+    if (h[i]) atomicAdd(&len_hist[i], h[i]);
+}
+
+// pass 2: order[pos] = t with pieces sorted by descending length
+static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint32_t* __restrict__ plen,
+                                                                     const uint32_t* __restrict__ po1, uint32_t TB,
+                                                                     const uint32_t* __restrict__ len_hist,
+                                                                     uint32_t* __restrict__ cursor,
+                                                                     uint32_t* __restrict__ order) {
+  __shared__ uint32_t base[kMaxPieceLen + 2];   // start of each length class in descending order
+  __shared__ uint32_t h[kMaxPieceLen + 1];      // local count, then reserved global start
+  __shared__ uint32_t wsum[4];
+  // descending exclusive prefix over lengths: base[L] = sum_{l > L} hist[l]
+  // (513 entries: two per thread, block scan over reversed index)
+  uint32_t tid = threadIdx.x;
+  uint32_t v0 = 0, v1 = 0, v2 = 0;
+  uint32_t r0 = 3 * tid, r1 = 3 * tid + 1, r2 = 3 * tid + 2;   // reversed positions: length = kMax - r
+  if (r0 <= kMaxPieceLen) v0 = len_hist[kMaxPieceLen - r0];
+  if (r1 <= kMaxPieceLen) v1 = len_hist[kMaxPieceLen - r1];
+  if (r2 <= kMaxPieceLen) v2 = len_hist[kMaxPieceLen - r2];
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(v0 + v1 + v2, wsum, tot);
+  if (r0 <= kMaxPieceLen) base[kMaxPieceLen - r0] = ex;
+  if (r1 <= kMaxPieceLen) base[kMaxPieceLen - r1] = ex + v0;
+  if (r2 <= kMaxPieceLen) base[kMaxPieceLen - r2] = ex + v0 + v1;
+  for (uint32_t i = tid; i <= kMaxPieceLen; i += 256u) h[i] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256u + tid;
+  uint32_t total = po1[TB];
+  uint32_t len = 0, local = 0;
+  bool valid = t < total;
+  if (valid) {
+    len = plen[t];
+    local = atomicAdd(&h[len], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i <= kMaxPieceLen; i += 256u) {
+    uint32_t c = h[i];
+    if (c) h[i] = atomicAdd(&cursor[i], c);
+  }
+  __syncthreads();
+  if (valid) order[base[len] + h[len] + local] = t;
+}
+
 // level 0: items are sorted point indices; piece j of bucket b covers entries
-// [off0[b] + j*K0, min(off0[b] + cnt0[b], +K0)).
+// [off0[b] + j*K0, min(off0[b] + cnt0[b], +K0)). Threads take pieces in `order` (longest first).
 template <class F>
 static __global__ __launch_bounds__(256) void msm_accum0_kernel(const void* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ cnt0,
                                                          const uint32_t* __restrict__ off0,
-                                                         const uint32_t* __restrict__ po1, uint32_t TB, uint32_t K0,
+                                                         const uint32_t* __restrict__ po1,
+                                                         const uint32_t* __restrict__ order,
+                                                         const uint32_t* __restrict__ pbkt, uint32_t TB, uint32_t K0,
                                                          void* __restrict__ buckets, void* __restrict__ P1) {
-  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  uint32_t slot = blockIdx.x * 256u + threadIdx.x;
   uint32_t total = po1[TB];
-  if (t >= total) return;
-  uint32_t b = find_bucket(po1, TB, t);
+  if (slot >= total) return;
+  uint32_t t = order[slot];
+  uint32_t b = pbkt[t];
   uint32_t j = t - po1[b];
   uint32_t cnt = cnt0[b];
   uint32_t start = off0[b] + j * K0;
@@ -434,6 +511,8 @@ inline size_t msm_workspace_bytes(const MsmPlan& p) {
   bytes += al(T * 4) * 2;                   // rank, sorted
   bytes += al(((size_t)p.TB / kScanTile + 2) * 4);
   bytes += al(64);
+  bytes += al(p1 * 4) * 3;                  // pbkt, plen, order
+  bytes += al((kMaxPieceLen + 1) * 4 * 2);  // len_hist, cursor
   bytes += al((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
   bytes += al(p1 * MsmSizes<F>::kXyzz);            // P1
   bytes += al(p2 * MsmSizes<F>::kXyzz);            // P2
@@ -469,6 +548,11 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   char* buckets = ws.take<char>((size_t)p.TB * MsmSizes<F>::kXyzz);
   size_t p1_cap = T_max / p.K0 + p.TB + 1;
   size_t p2_cap = p1_cap / 2 + 1;
+  uint32_t* pbkt = ws.take<uint32_t>(p1_cap);
+  uint32_t* plen = ws.take<uint32_t>(p1_cap);
+  uint32_t* order = ws.take<uint32_t>(p1_cap);
+  uint32_t* len_hist = ws.take<uint32_t>(2 * (kMaxPieceLen + 1));
+  uint32_t* len_cursor = len_hist + (kMaxPieceLen + 1);
   char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
   char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
   const uint32_t segs = p.TB / MsmPlan::SEG;
@@ -480,6 +564,7 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
 
   ZK_HIP(hipMemsetAsync(counts, 0, (size_t)p.TB * 4, st));
   ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
+  ZK_HIP(hipMemsetAsync(len_hist, 0, 2 * (kMaxPieceLen + 1) * 4, st));
   ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
   const uint32_t nblk = (p.n + 255) / 256;
   if (p.n) {
@@ -495,10 +580,16 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   ZK_HIP(hipStreamSynchronize(st));
   const uint32_t max_count = hb[1];
   const uint32_t total1 = hb[2];
-  if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
+  if (accum_ms && !total1) ZK_HIP(hipEventRecord(lane.ev0, st));
   if (total1) {
-    hipLaunchKernelGGL((msm_accum0_kernel<F>), dim3((total1 + 255) / 256), dim3(256), 0, st, d_bases, sorted, counts,
-                       off0, po_a, p.TB, p.K0, (void*)buckets, (void*)P1);
+    const uint32_t pgrid = (total1 + 255) / 256;
+    hipLaunchKernelGGL(msm_piece_len_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)counts,
+                       (const uint32_t*)po_a, p.TB, p.K0, pbkt, plen, len_hist);
+    hipLaunchKernelGGL(msm_piece_order_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)plen,
+                       (const uint32_t*)po_a, p.TB, (const uint32_t*)len_hist, len_cursor, order);
+    if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
+    hipLaunchKernelGGL((msm_accum0_kernel<F>), dim3(pgrid), dim3(256), 0, st, d_bases, sorted, counts, off0, po_a,
+                       (const uint32_t*)order, (const uint32_t*)pbkt, p.TB, p.K0, (void*)buckets, (void*)P1);
   }
   if (accum_ms) ZK_HIP(hipEventRecord(lane.ev1, st));
   // further levels while some bucket still has more than one partial sum
