@@ -45,6 +45,78 @@ def dlog_expected(limbs, a, b, i0):
     return (a * s0 + b * s1) % R_MOD
 
 
+# circuit shapes of the reference's own test runs (SURVEY.md 8 "Sizes at BASELINE.json configs")
+PROVE_SHAPES = {
+    16: (60000, 2, "test-size synthetic"),
+    21: (2083343, 1, "layer_one(2 sigs) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:17-23"),
+    25: (21356921, 2, "layer_two(2,12) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:33-39"),
+    26: (61197000, 1, "synthetic layer_one(128 sigs) shape, tests/old/128_sigs/benchmarks.txt:4-10"),
+}
+
+
+def bench_prove(args, zk, dist, rank, world, local_rank, dev):
+    """Full Groth16 prove against a key + witness resident in HBM. N>1: whole proofs are independent
+    (the reference runs one prover process per batch, full_workflow.sh:552): replicas, no collective."""
+    import torch
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    k = int(args.workload[len("prove_2p"):])
+    m, n_pub, what = PROVE_SHAPES[k]
+    ctx = zk.Context(local_rank)
+    circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010 + rank, witness_like=True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        circ.prove(0, 0)
+    sync()
+    t0 = time.perf_counter()
+    acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
+    for i in range(args.steps):
+        pts, _ = circ.prove(0, 0)
+        acc["h_chain"] += ctx.last_ms(3)
+        acc["msm_phase"] += ctx.last_ms(4)
+        acc["prove"] += ctx.last_ms(5)
+        acc["h_msm_accum"] += ctx.last_ms(1)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not circ.check(pts, 0, 0):
+        raise SystemExit("bench.py: proof failed the known-dlog check (pi_a / pi_b)")
+    if rank == 0:
+        n = 1 << k
+        ncoef = circ.n_coef
+        # SURVEY.md 8d full-prove formula
+        alg = 96 * (3 * m - n_pub - 1) + 160 * m + 96 * n + 6 * 64 * n + 76 * ncoef + 96 * n + 128 * n
+        sec = elapsed / args.steps
+        line = {
+            "metric": "Groth16 proofs/sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic",
+            "config": {"workload": "full Groth16 prove, domain 2^%d, %d wires, %d public (%s); key and witness "
+                                   "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
+                       "n_coefs": ncoef, "parallelism": "replicas (one proof per GPU)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
+                         "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg,
+                         "phase_ms": {kk: v / args.steps for kk, v in acc.items()}},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    circ.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,12 +147,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    if args.workload.startswith("prove_2p"):
+        return bench_prove(args, zk, dist, rank, world, local_rank, dev)
     if args.workload.startswith("msm_g1_2p"):
         logn = int(args.workload[len("msm_g1_2p"):])
     else:
         raise SystemExit("unknown workload " + args.workload)
     n_local = 1 << logn
     ctx = zk.Context(local_rank)
+    if logn > 27:
+        raise SystemExit("msm workload limited to 2^27 points per GPU")
 
     # ---- synthetic inputs, resident in HBM: bases (a + i*b)*G with known discrete logs, uniform scalars
     seeds = random.Random(0x5EED0001)

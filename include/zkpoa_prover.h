@@ -79,6 +79,19 @@ int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey,
                 const uint8_t* r_le, const uint8_t* s_le,
                 uint8_t proof_points[256], uint8_t* public_le, unsigned long public_capacity);
 
+/* Same two calls for data that already lives in HBM (what bench.py times for the prove workloads;
+ * also the hook for a device-native zkey cache). The five point sections stay owned
+ * by the caller and must outlive the handle; d_coef_records = n_coefs 44-byte records of section 4;
+ * header_points = alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128), wire format. */
+int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                           const void* d_A, const void* d_B1, const void* d_B2, const void* d_C, const void* d_H,
+                           const void* d_coef_records, uint64_t n_coefs, const uint8_t header_points[448],
+                           zkpoa_zkey** zkey);
+/* d_witness: n_vars x 32 B standard form on the device (w[0] = 1). */
+int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
+                       const uint8_t* r_le, const uint8_t* s_le,
+                       uint8_t proof_points[256], uint8_t* public_le, unsigned long public_capacity);
+
 /* proof_points / public -> JSON text. style 0 = rapidsnark bytes, 1 = snarkjs bytes
  * (SURVEY.md 8a row a11). Size protocol as groth16_prover. */
 int zkpoa_proof_to_json(const uint8_t proof_points[256], int style, char* buffer, unsigned long* size);

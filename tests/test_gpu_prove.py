@@ -185,3 +185,30 @@ def test_python_host_mirror_groth16_prove(zk, tmp_path):
     proof = json.loads((tmp_path / "p.json").read_text())
     public = json.loads((tmp_path / "u.json").read_text())
     assert g16.verify(vkey, public, proof)
+
+
+# ---- device-resident synthetic key with known discrete logs --------------------------------
+@pytest.mark.parametrize("witness_like", [False, True])
+def test_synthetic_circuit_prove_known_dlog(ctx, zk, witness_like):
+    """2^16-domain synthetic key generated in HBM: pi_a, pi_b, pi_c must equal the discrete-log
+    expectation, with the H scalars taken from the C oracle (independent of the GPU chain)."""
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    circ = SyntheticCircuit(zk, ctx, 16, 60000, n_public=2, seed=77, witness_like=witness_like)
+    try:
+        coeffs, wit = circ.coeff_section_bytes(), circ.witness_bytes()
+        P = co.h_scalars(coeffs, wit, circ.m, 16)
+        assert ctx.h_scalars(coeffs, wit, circ.m, 16) == P
+        rng = random.Random(3)
+        for (r_, s_) in ((0, 0), (rng.randrange(R), rng.randrange(R))):
+            pts, pub = circ.prove(r_, s_)
+            assert circ.check(pts, r_, s_, P)
+            assert pub == wit[32:32 * 3]
+        # tampering with one witness value must change the proof
+        pts0, _ = circ.prove(0, 0)
+        import torch
+        circ.d_witness[32 * 5] ^= 1
+        pts1, _ = circ.prove(0, 0)
+        circ.d_witness[32 * 5] ^= 1
+        assert pts0 != pts1
+    finally:
+        circ.close()

@@ -27,6 +27,7 @@ EXPORTS = [
     "groth16_prover", "groth16_prover_zkey_file",
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
+    "zkpoa_zkey_load_device", "zkpoa_prove_device",
     "zkpoa_proof_to_json", "zkpoa_public_to_json",
     "zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_ntt", "zkpoa_h_scalars",
     "zkpoa_msm_g1_device", "zkpoa_msm_g2_device", "zkpoa_ntt_device",
@@ -50,6 +51,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ZkpoaError("libzkpoa_prover.so not built (%s): run `python -c 'import __graft_entry__ as g; "
                              "g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64. If our library (linked
+        # against /opt/rocm) is loaded first, torch's HSA copy later fails to open the device ("No HIP GPUs
+        # are available"); loaded in this order both HIP runtimes share torch's HSA runtime (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         c_void_pp = ctypes.POINTER(ctypes.c_void_p)
         ul_p = ctypes.POINTER(ctypes.c_ulong)
@@ -85,6 +93,10 @@ def lib():
         L.zkpoa_zkey_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         L.zkpoa_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
                                   ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_zkey_load_device.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint] + \
+            [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
+        L.zkpoa_prove_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p,
+                                         ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
@@ -215,6 +227,28 @@ class Context:
     # ---- proving key + prove -----------------------------------------------------------------
     def load_zkey(self, zkey_bytes):
         return ZKey(self, zkey_bytes)
+
+    def load_zkey_device(self, n_vars, n_public, log_domain, d_A, d_B1, d_B2, d_C, d_H, d_coefs, n_coefs,
+                         header_points):
+        """Proving key from device-resident sections (device pointers as ints); the caller keeps them alive."""
+        key = ZKey.__new__(ZKey)
+        key._ctx = self
+        key._h = ctypes.c_void_p()
+        self._check(lib().zkpoa_zkey_load_device(self._h, n_vars, n_public, log_domain, d_A, d_B1, d_B2, d_C, d_H,
+                                                 d_coefs, n_coefs, bytes(header_points), ctypes.byref(key._h)),
+                    "zkpoa_zkey_load_device")
+        return key
+
+    def prove_device(self, zkey, d_witness, r=None, s=None):
+        """Prove with the witness already in HBM -> (proof_points[256], public bytes)."""
+        rb = None if r is None else int(r).to_bytes(32, "little")
+        sb = None if s is None else int(s).to_bytes(32, "little")
+        proof = ctypes.create_string_buffer(256)
+        npub = zkey.info()[1]
+        pub = ctypes.create_string_buffer(max(1, 32 * npub))
+        self._check(lib().zkpoa_prove_device(self._h, zkey._h, d_witness, rb, sb, proof, pub, 32 * npub),
+                    "zkpoa_prove_device")
+        return proof.raw, pub.raw[:32 * npub]
 
     def prove(self, zkey, wtns_bytes, r=None, s=None):
         """-> (proof_points[256 bytes], public[nPublic*32 bytes])"""

@@ -102,8 +102,13 @@ struct zkpoa_zkey {
   void* d_vals = nullptr;
   void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
   void* d_witness = nullptr;  // nVars * 32 B
+  bool owns_points = true;    // false when the point sections belong to the caller (zkpoa_zkey_load_device)
   void release() {
-    void* ptrs[] = {dA, dB1, dB2, dC, dH, d_row_ptr, d_sig, d_vals, d_abc, d_witness};
+    void* pts[] = {dA, dB1, dB2, dC, dH};
+    if (owns_points)
+      for (void* p : pts)
+        if (p) (void)hipFree(p);
+    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = nullptr;
@@ -112,6 +117,39 @@ struct zkpoa_zkey {
 };
 
 namespace {
+
+// CSR of the coefficient list by output row (2*c + m); d_recs = device copy of the 44-byte records.
+// Also allocates the A/B/C work area and the witness buffer, and builds the NTT tables.
+void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs) {
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  const uint32_t rows = 2 * zk->domain;
+  const uint64_t n = zk->domain, m = zk->nVars;
+  if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * n * 32));
+  if (!zk->d_witness) ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
+  DevBuf d_cnt((size_t)rows * 4), d_rank((size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4),
+      d_bs(((size_t)rows / kScanTile + 2) * 4), d_misc(64);
+  ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
+  ZK_HIP(hipMalloc(&zk->d_sig, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
+  ZK_HIP(hipMalloc(&zk->d_vals, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 32));
+  ZK_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)rows * 4, st));
+  ZK_HIP(hipMemsetAsync(d_misc.p, 0, 64, st));
+  uint32_t* misc = (uint32_t*)d_misc.p;
+  if (zk->nCoefs) {
+    uint32_t grid = (uint32_t)((zk->nCoefs + 255) / 256);
+    hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs, zk->domain,
+                       zk->nVars, (uint32_t*)d_cnt.p, (uint32_t*)d_rank.p, misc + 4);
+    scan_u32(st, (const uint32_t*)d_cnt.p, rows, 0, 0, zk->d_row_ptr, (uint32_t*)d_bs.p, misc, nullptr);
+    hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
+                       (const uint32_t*)zk->d_row_ptr, (const uint32_t*)d_rank.p, zk->d_sig, zk->d_vals);
+  } else {
+    ZK_HIP(hipMemsetAsync(zk->d_row_ptr, 0, ((size_t)rows + 1) * 4, st));
+  }
+  uint32_t herr = 0;
+  ZK_HIP(hipMemcpyAsync(&herr, misc + 4, 4, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+  if (herr) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
+}
 
 zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size) {
   Sections secs = parse_binfile(buf, size, "zkey", 2);
@@ -162,43 +200,15 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     zk->dB2 = dev_upload(s7.p, s7.len);
     zk->dC = dev_upload(s8.p, s8.len);
     zk->dH = dev_upload(s9.p, s9.len);
-    ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * n * 32));
-    ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
-
-    // CSR of the coefficient list by output row (2*c + m)
     hipStream_t st = ctx->dev.lanes[0].stream;
-    const uint32_t rows = 2 * zk->domain;
     void* d_recs = dev_upload(s4.p + 4, zk->nCoefs * 44);
-    uint32_t *d_cnt = nullptr, *d_rank = nullptr, *d_bs = nullptr, *d_misc = nullptr;
-    ZK_HIP(hipMalloc(&d_cnt, (size_t)rows * 4));
-    ZK_HIP(hipMalloc(&d_rank, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
-    ZK_HIP(hipMalloc(&d_bs, ((size_t)rows / kScanTile + 2) * 4));
-    ZK_HIP(hipMalloc(&d_misc, 64));
-    ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
-    ZK_HIP(hipMalloc(&zk->d_sig, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
-    ZK_HIP(hipMalloc(&zk->d_vals, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 32));
-    ZK_HIP(hipMemsetAsync(d_cnt, 0, (size_t)rows * 4, st));
-    ZK_HIP(hipMemsetAsync(d_misc, 0, 64, st));
-    if (zk->nCoefs) {
-      uint32_t grid = (uint32_t)((zk->nCoefs + 255) / 256);
-      hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
-                         zk->domain, zk->nVars, d_cnt, d_rank, d_misc + 4);
-      scan_u32(st, d_cnt, rows, 0, 0, zk->d_row_ptr, d_bs, d_misc, nullptr);
-      hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
-                         (const uint32_t*)zk->d_row_ptr, (const uint32_t*)d_rank, zk->d_sig, zk->d_vals);
-    } else {
-      ZK_HIP(hipMemsetAsync(zk->d_row_ptr, 0, ((size_t)rows + 1) * 4, st));
+    try {
+      build_csr(ctx, zk.get(), d_recs);
+    } catch (...) {
+      (void)hipFree(d_recs);
+      throw;
     }
-    uint32_t herr[2] = {0, 0};
-    ZK_HIP(hipMemcpyAsync(herr, d_misc + 4, 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    ZK_HIP(hipGetLastError());
     (void)hipFree(d_recs);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_rank);
-    (void)hipFree(d_bs);
-    (void)hipFree(d_misc);
-    if (herr[0]) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
     ntt_prepare(ctx, st, zk->power);
     ZK_HIP(hipStreamSynchronize(st));
   } catch (...) {
@@ -264,22 +274,14 @@ WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
   return w;
 }
 
-void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
-                const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
-                uint64_t public_cap) {
+// The witness is already in zk->d_witness (device).
+void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, const uint8_t* s_le,
+                uint8_t proof_points[256]) {
   auto t0 = std::chrono::steady_clock::now();
-  WtnsView w = parse_wtns(wtns, wtns_size);
-  if (w.n != zk->nVars)
-    throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
-                                                         ", witness: " + std::to_string(w.n));
-  if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
   uint8_t rb[32], sb[32];
   if (r_le) memcpy(rb, r_le, 32); else random_scalar(rb);
   if (s_le) memcpy(sb, s_le, 32); else random_scalar(sb);
-
   Lane& l0 = ctx->dev.lanes[0];
-  ZK_HIP(hipMemcpyAsync(zk->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, l0.stream));
-  ZK_HIP(hipStreamSynchronize(l0.stream));
 
   // four witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back)
   uint8_t outA[64], outB1[64], outB2[128], outC[64], outH[64];
@@ -351,13 +353,27 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   h_affine_to_bytes<HFq>(h_to_affine(pi_a), proof_points);
   h_affine_to_bytes<HFq2>(h_to_affine(pi_b), proof_points + 64);
   h_affine_to_bytes<HFq>(h_to_affine(pi_c), proof_points + 192);
-  memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
 
   auto t1 = std::chrono::steady_clock::now();
   ctx->ms[4] = std::chrono::duration<float, std::milli>(tm1 - tm0).count();
   ctx->ms[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
   ctx->ms[0] = msm_ms[0][0];
   ctx->ms[1] = msm_ms[0][1];
+}
+
+void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
+                const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
+                uint64_t public_cap) {
+  WtnsView w = parse_wtns(wtns, wtns_size);
+  if (w.n != zk->nVars)
+    throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
+                                                         ", witness: " + std::to_string(w.n));
+  if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+  Lane& l0 = ctx->dev.lanes[0];
+  ZK_HIP(hipMemcpyAsync(zk->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, l0.stream));
+  ZK_HIP(hipStreamSynchronize(l0.stream));
+  prove_core(ctx, zk, r_le, s_le, proof_points);
+  memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
 }
 
 // ---- JSON (byte formats pinned by the reference's committed fixtures) --------
@@ -565,6 +581,70 @@ extern "C" int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey, const voi
     uint8_t dummy[1];
     prove_impl(ctx, zkey, reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, r_le, s_le, proof_points,
                public_le ? public_le : dummy, public_le ? public_capacity : (zkey->nPublic ? 0 : 1));
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                                      const void* d_A, const void* d_B1, const void* d_B2, const void* d_C,
+                                      const void* d_H, const void* d_coef_records, uint64_t n_coefs,
+                                      const uint8_t header_points[448], zkpoa_zkey** out) {
+  if (!ctx || !out || !header_points) return PROVER_ERROR;
+  *out = nullptr;
+  std::unique_ptr<zkpoa_zkey> zk(new zkpoa_zkey());
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (log_domain > 28 || n_vars == 0 || n_vars > (1ull << 28) || n_public + 1 > n_vars || n_coefs > 0xffffffffull)
+      throw ProverError(PROVER_ERROR, "zkey_load_device: size out of range");
+    zk->nVars = (uint32_t)n_vars;
+    zk->nPublic = (uint32_t)n_public;
+    zk->power = log_domain;
+    zk->domain = 1u << log_domain;
+    zk->nCoefs = n_coefs;
+    zk->owns_points = false;
+    zk->dA = const_cast<void*>(d_A);
+    zk->dB1 = const_cast<void*>(d_B1);
+    zk->dB2 = const_cast<void*>(d_B2);
+    zk->dC = const_cast<void*>(d_C);
+    zk->dH = const_cast<void*>(d_H);
+    zk->alpha1 = h_affine_from_bytes<HFq>(header_points);
+    zk->beta1 = h_affine_from_bytes<HFq>(header_points + 64);
+    zk->beta2 = h_affine_from_bytes<HFq2>(header_points + 128);
+    zk->delta1 = h_affine_from_bytes<HFq>(header_points + 256);
+    zk->delta2 = h_affine_from_bytes<HFq2>(header_points + 320);
+    build_csr(ctx, zk.get(), d_coef_records);
+    ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power);
+    ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));
+  } catch (const ProverError& e) {
+    zk->release();
+    ctx->last_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    zk->release();
+    ctx->last_error = e.what();
+    return PROVER_ERROR;
+  }
+  *out = zk.release();
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
+                                  const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256],
+                                  uint8_t* public_le, unsigned long public_capacity) {
+  if (!ctx || !zkey || !d_witness || !proof_points) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
+      throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    if (d_witness != zkey->d_witness)
+      ZK_HIP(hipMemcpyAsync(zkey->d_witness, d_witness, (size_t)zkey->nVars * 32, hipMemcpyDeviceToDevice, st));
+    if (public_le && zkey->nPublic)
+      ZK_HIP(hipMemcpyAsync(public_le, reinterpret_cast<const char*>(d_witness) + 32, (size_t)zkey->nPublic * 32,
+                            hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    prove_core(ctx, zkey, r_le, s_le, proof_points);
   }
   ZK_PROVER_CATCH(ctx)
   return PROVER_OK;

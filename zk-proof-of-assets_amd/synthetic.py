@@ -1,0 +1,169 @@
+"""Synthetic Groth16 workloads generated directly in HBM.
+
+The reference's circuits cannot be compiled offline (no circom; submodules empty), so the
+measurement configs use a circuit of the same *shape* (BASELINE.json configs[2..4]): n_vars wires,
+domain 2^k, constraints (w[a] + w[b]) * w[d] = ..., 3 coefficients per constraint plus the
+nPublic+1 public rows -- with every base point a KNOWN multiple of the generator:
+
+    section X, index i:   P_i = (a_X + i * b_X) * G        (B1 and B2 share a_B, b_B)
+    header:               alpha1 = al*G1, beta1 = be*G1, beta2 = be*G2, delta1 = de*G1, delta2 = de*G2
+
+so the expected proof is a discrete-log computation in Fr (O(n) integer work, no CPU MSM):
+    a = sum w_i A_i + al + r de,  b = sum w_i B_i + be + s de,
+    c = sum w_i C_i + sum P_j H_j + s a + r b - r s de;     proof = (a*G1, b*G2, c*G1).
+Such a key is not a valid trusted setup (proofs do not verify); it exercises exactly the same
+kernels on the same data volumes, which is what the timing configs need, and every group element of
+the output is still checked exactly.
+"""
+import random
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def dlog_sums(limbs, i0=0):
+    """(sum k_i, sum (i0 + i) * k_i) as exact Python ints; limbs = uint64 array [n, 4] (LE limbs)."""
+    import numpy as np
+    n = limbs.shape[0]
+    s0 = 0
+    s1 = 0
+    chunk = 1 << 20
+    for start in range(0, n, chunk):
+        blk = limbs[start:start + chunk]
+        idx = np.arange(i0 + start, i0 + start + blk.shape[0], dtype=np.uint64)
+        for j in range(4):
+            col = blk[:, j]
+            for piece in range(4):
+                part = (col >> np.uint64(16 * piece)) & np.uint64(0xFFFF)
+                sh = 64 * j + 16 * piece
+                s0 += int(part.sum(dtype=np.uint64)) << sh
+                # idx < 2^28, part < 2^16, <= 2^20 terms: sum < 2^64
+                s1 += int(np.dot(idx, part)) << sh
+    return s0, s1
+
+
+def _mont_g1_generator():
+    one = (1 << 256) % Q_MOD
+    two = (2 << 256) % Q_MOD
+    return one.to_bytes(32, "little") + two.to_bytes(32, "little")
+
+
+_G2_STD = (
+    10857046999023057135944570762232829481370756359578518086990519993285655852781,
+    11559732032986387107991004021392285783925812861821192530917403151452391805634,
+    8495653923123431417604973247489272438418190587263600148770280649306958101930,
+    4082367875863433681332203403145435568316851327593401208105741076214120093531,
+)
+
+
+def _mont_g2_generator():
+    return b"".join(((v << 256) % Q_MOD).to_bytes(32, "little") for v in _G2_STD)
+
+
+class SyntheticCircuit:
+    """Device-resident synthetic proving key + witness with known discrete logs."""
+
+    def __init__(self, zk, ctx, log_domain, n_vars, n_public=1, seed=0x5EED0010, witness_like=False, device=None):
+        import numpy as np
+        import torch
+        self.zk, self.ctx = zk, ctx
+        self.k, self.n, self.m, self.n_public = log_domain, 1 << log_domain, n_vars, n_public
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        rng = random.Random(seed)
+        self.par = {x: (rng.randrange(R_MOD), rng.randrange(R_MOD)) for x in ("A", "B", "C", "H")}
+        self.hdr = {x: rng.randrange(1, 1 << 64) for x in ("alpha", "beta", "delta")}
+        m, n = self.m, self.n
+        nC = m - n_public - 1
+        self.d_A = torch.empty(m * 64, dtype=torch.uint8, device=dev)
+        self.d_B1 = torch.empty(m * 64, dtype=torch.uint8, device=dev)
+        self.d_B2 = torch.empty(m * 128, dtype=torch.uint8, device=dev)
+        self.d_C = torch.empty(max(nC, 1) * 64, dtype=torch.uint8, device=dev)
+        self.d_H = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        ctx.gen_bases_g1_device(*self.par["A"], 0, m, self.d_A.data_ptr())
+        ctx.gen_bases_g1_device(*self.par["B"], 0, m, self.d_B1.data_ptr())
+        ctx.gen_bases_g2_device(*self.par["B"], 0, m, self.d_B2.data_ptr())
+        ctx.gen_bases_g1_device(*self.par["C"], 0, nC, self.d_C.data_ptr())
+        ctx.gen_bases_g1_device(*self.par["H"], 0, n, self.d_H.data_ptr())
+        # coefficient records: constraint c has A-terms (a_c, 1), (b_c, 1) and B-term (d_c, 1); then public rows
+        n_cons = n - n_public - 1
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed & 0x7FFFFFFF)
+        sig = torch.randint(0, m, (n_cons, 3), generator=g, dtype=torch.int32)
+        cidx = torch.arange(n_cons, dtype=torch.int32)
+        r2 = (1 << 512) % R_MOD                           # coefficient 1 is stored as 1 * R^2
+        val = torch.tensor([(r2 >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=torch.int64).to(torch.int32)
+        n_coef = 3 * n_cons + n_public + 1
+        recs = torch.empty((n_coef, 11), dtype=torch.int32)
+        recs[:, 3:] = val
+        for t, mat in enumerate((0, 0, 1)):
+            blk = recs[t * n_cons:(t + 1) * n_cons]
+            blk[:, 0] = mat
+            blk[:, 1] = cidx
+            blk[:, 2] = sig[:, t]
+        pub = recs[3 * n_cons:]
+        pub[:, 0] = 0
+        pub[:, 1] = torch.arange(n_cons, n_cons + n_public + 1, dtype=torch.int32)
+        pub[:, 2] = torch.arange(0, n_public + 1, dtype=torch.int32)
+        self.n_coef = n_coef
+        self.recs_host = recs                              # [n_coef, 11] int32 == 44-byte records
+        self.d_recs = recs.to(dev)
+        # witness: w[0] = 1, rest uniform 252-bit (or witness-like: 55% bits, 35% < 2^64, 10% uniform)
+        nr = np.random.default_rng(seed + 1)
+        limbs = nr.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + nr.integers(0, 2, size=(m, 4), dtype=np.uint64)
+        limbs[:, 3] &= np.uint64((1 << 60) - 1)
+        if witness_like:
+            u = nr.random(m)
+            small = u < 0.55
+            limbs[small, 1:] = 0
+            limbs[small, 0] = nr.integers(0, 2, size=int(small.sum()), dtype=np.uint64)
+            limbs[(u >= 0.55) & (u < 0.9), 1:] = 0
+        limbs[0] = (1, 0, 0, 0)
+        self.w_limbs = limbs
+        self.d_witness = torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).to(dev)
+        G1, G2 = _mont_g1_generator(), _mont_g2_generator()
+        hp = (zk.g1_mul(G1, self.hdr["alpha"]) + zk.g1_mul(G1, self.hdr["beta"]) + zk.g2_mul(G2, self.hdr["beta"]) +
+              zk.g1_mul(G1, self.hdr["delta"]) + zk.g2_mul(G2, self.hdr["delta"]))
+        self.key = ctx.load_zkey_device(m, n_public, log_domain, self.d_A.data_ptr(), self.d_B1.data_ptr(),
+                                        self.d_B2.data_ptr(), self.d_C.data_ptr(), self.d_H.data_ptr(),
+                                        self.d_recs.data_ptr(), n_coef, hp)
+        self._G1, self._G2 = G1, G2
+
+    def coeff_section_bytes(self):
+        """Payload of zkey section 4 (u32 count + records) for the host-buffer entry points."""
+        return int(self.n_coef).to_bytes(4, "little") + self.recs_host.numpy().tobytes()
+
+    def witness_bytes(self):
+        return self.w_limbs.tobytes()
+
+    def prove(self, r=0, s=0):
+        return self.ctx.prove_device(self.key, self.d_witness.data_ptr(), r, s)
+
+    def expected_dlogs(self, r, s, h_scalars_bytes=None):
+        """(a, b, c) with c = None when the H scalars are not supplied."""
+        import numpy as np
+        s0, s1 = dlog_sums(self.w_limbs)
+        sums = {x: (self.par[x][0] * s0 + self.par[x][1] * s1) % R_MOD for x in ("A", "B")}
+        de = self.hdr["delta"]
+        a = (sums["A"] + self.hdr["alpha"] + r * de) % R_MOD
+        b = (sums["B"] + self.hdr["beta"] + s * de) % R_MOD
+        c = None
+        if h_scalars_bytes is not None:
+            wc = self.w_limbs[self.n_public + 1:]
+            c0, c1 = dlog_sums(wc)
+            csum = (self.par["C"][0] * c0 + self.par["C"][1] * c1) % R_MOD
+            P = np.frombuffer(h_scalars_bytes, dtype=np.uint64).reshape(-1, 4)
+            h0, h1 = dlog_sums(P)
+            hsum = (self.par["H"][0] * h0 + self.par["H"][1] * h1) % R_MOD
+            c = (csum + hsum + s * a + r * b - r * s % R_MOD * de) % R_MOD
+        return a, b, c
+
+    def check(self, proof_points, r, s, h_scalars_bytes=None):
+        """True iff pi_a, pi_b (and pi_c when H scalars are given) equal the known-dlog expectation."""
+        a, b, c = self.expected_dlogs(r, s, h_scalars_bytes)
+        ok = proof_points[0:64] == self.zk.g1_mul(self._G1, a) and proof_points[64:192] == self.zk.g2_mul(self._G2, b)
+        if c is not None:
+            ok = ok and proof_points[192:256] == self.zk.g1_mul(self._G1, c)
+        return ok
+
+    def close(self):
+        self.key.close()
