@@ -8,17 +8,17 @@
 // Inputs are exactly the reference's wire formats: bases affine / Montgomery / 64 B (G1) or
 // 128 B (G2) as in .zkey sections 5-9, scalars 32 B little-endian standard form as in .wtns.
 //
-// Pipeline (all kernels on one stream; one 8-byte read-back to size the launches):
-//   1 count    : scalar -> sign-normalised (s > r/2 -> r-s, negate base) signed c-bit digits;
-//                per-(window,bucket) histogram with global atomics; the dominant hot bucket of
-//                real witnesses (|digit| = 1, i.e. scalars 0/1/-1) is aggregated per wavefront
-//                with a 64-bit ballot so it costs one atomic per wave, not one per lane.
-//   2 scan     : exclusive scan of the histogram (bucket offsets) + piece offsets.
-//   3 scatter  : counting sort of point indices by (window,bucket) using the ranks from 1.
-//   4 accumulate (level 0): buckets are cut into pieces of <= K0 entries; one thread sums one
-//                piece with XYZZ mixed additions (gather of 64/128-B affine bases). Pieces make
-//                the work per thread bounded whatever the scalar distribution; buckets with
-//                more than one piece are finished by further levels over the partial sums.
+// Pipeline (all kernels on one stream; one 16-byte read-back to size the launches):
+//   1 digits   : scalar -> sign-normalised (s > r/2 -> r-s, negate base) signed c-bit digits.
+//   2 sort     : two-level MSD counting sort of (point, window) entries by bucket on LDS histograms
+//                (msm_sort.hip.h): per-task LDS histogram, one global atomic per (task, bin) to reserve
+//                ranges, scan, LDS-ranked scatter. The hot key of real witnesses (|digit| = 1, i.e.
+//                scalars 0/1/-1) is aggregated per wavefront with a 64-bit ballot.
+//   3 scan     : exclusive scans (bucket offsets, piece offsets).
+//   4 accumulate (level 0): buckets are cut into pieces of <= K0 entries, pieces are ordered by length
+//                (longest first) and one thread sums one piece with XYZZ mixed additions (gather of
+//                64/128-B affine bases). Work per thread is bounded whatever the scalar distribution;
+//                buckets with more than one piece are finished by further levels over the partial sums.
 //   5 reduce   : sum_b b*B[b] per window: threads take 8-bucket segments (running sums), weight
 //                them by the segment index, then an LDS tree sums segments per window.
 //   6 host     : W window sums -> Horner over 2^c on the host (O(W*c) group ops).
@@ -95,43 +95,6 @@ ZK_DEV void load_scalar(const void* scalars, uint32_t i, uint32_t (&s)[8]) {
   uint4 a = p[0], b = p[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
   s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-}
-
-// ---- 1: count -------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void msm_count_kernel(const void* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                        uint32_t W, uint32_t* __restrict__ counts,
-                                                        uint32_t* __restrict__ rank) {
-  uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  bool valid = i < n;
-  uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) load_scalar(scalars, i, s);
-  (void)scalar_normalize(s);
-  const uint32_t Nb = 1u << (c - 1), mask = (1u << c) - 1u;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t carry = 0;
-  for (uint32_t w = 0; w < W; w++) {
-    uint32_t d = (s[0] & mask) + carry;
-    scalar_shr(s, c);
-    carry = d > Nb ? 1u : 0u;
-    uint32_t mag = carry ? (mask + 1u - d) : d;
-    bool emit = valid && mag != 0;
-    uint32_t key = w * Nb + mag - 1u;
-    bool is_hot = emit && mag == 1u;
-    unsigned long long hot = __ballot(is_hot);
-    if (emit) {
-      uint32_t r;
-      if (is_hot) {
-        int leader = __ffsll((long long)hot) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&counts[key], (uint32_t)__popcll(hot));
-        base = __shfl(base, leader);
-        r = base + (uint32_t)__popcll(hot & ((1ull << lane) - 1ull));
-      } else {
-        r = atomicAdd(&counts[key], 1u);
-      }
-      rank[(size_t)w * n + i] = r;
-    }
-  }
 }
 
 // ---- 2: scan (u32, exclusive, n+1 outputs) ----------------------------------------------------
@@ -253,32 +216,6 @@ inline void scan_u32(hipStream_t st, const uint32_t* in, uint32_t n, int mode, u
                      out);
 }
 
-// ---- 3: scatter -----------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void msm_scatter_kernel(const void* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                          uint32_t W, const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ rank,
-                                                          uint32_t* __restrict__ sorted) {
-  uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8];
-  load_scalar(scalars, i, s);
-  bool neg = scalar_normalize(s);
-  const uint32_t Nb = 1u << (c - 1), mask = (1u << c) - 1u;
-  uint32_t carry = 0;
-  for (uint32_t w = 0; w < W; w++) {
-    uint32_t d = (s[0] & mask) + carry;
-    scalar_shr(s, c);
-    carry = d > Nb ? 1u : 0u;
-    uint32_t mag = carry ? (mask + 1u - d) : d;
-    if (mag != 0) {
-      uint32_t key = w * Nb + mag - 1u;
-      bool sign = (carry != 0) != neg;
-      uint32_t pos = offsets[key] + rank[(size_t)w * n + i];
-      sorted[pos] = i | (sign ? 0x80000000u : 0u);
-    }
-  }
-}
-
 // ---- 4: accumulate --------------------------------------------------------------------------
 // largest b in [0, nb) with po[b] <= t  (po has nb+1 entries, non-decreasing, po[nb] > t)
 ZK_DEV uint32_t find_bucket(const uint32_t* __restrict__ po, uint32_t nb, uint32_t t) {
@@ -289,6 +226,10 @@ ZK_DEV uint32_t find_bucket(const uint32_t* __restrict__ po, uint32_t nb, uint32
   }
   return lo;
 }
+
+}  // namespace zkpoa
+#include "msm_sort.hip.h"   // 1 + 3: digits and the two-level LDS bucket sort
+namespace zkpoa {
 
 // ---- 4a: order the pieces by length, longest first ----------------------------------------------
 // Piece lengths follow the bucket-count distribution (Poisson for uniform scalars), so lanes of one
@@ -508,7 +449,12 @@ inline size_t msm_workspace_bytes(const MsmPlan& p) {
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   bytes += al((size_t)p.TB * 4) * 2;        // counts, (spare)
   bytes += al(((size_t)p.TB + 1) * 4) * 4;  // off0, po_a, po_b, po_c
-  bytes += al(T * 4) * 2;                   // rank, sorted
+  SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  bytes += al(T * 4) * 2;                   // digits, sorted
+  bytes += al(T * 8);                       // coarse-sorted entries
+  bytes += al(((size_t)sp.SB + 1) * 4) * 3; // bin_cnt, bin_off, tpo
+  bytes += al((size_t)sp.chunks1 * sp.W * sp.bins * 4);
+  bytes += al((size_t)sp.tasks2_max * sp.F * 4);
   bytes += al(((size_t)p.TB / kScanTile + 2) * 4);
   bytes += al(64);
   bytes += al(p1 * 4) * 3;                  // pbkt, plen, order
@@ -541,7 +487,14 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   uint32_t* off0 = ws.take<uint32_t>(p.TB + 1);
   uint32_t* po_a = ws.take<uint32_t>(p.TB + 1);
   uint32_t* po_b = ws.take<uint32_t>(p.TB + 1);
-  uint32_t* rank = ws.take<uint32_t>(T_max);
+  const SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  uint32_t* digits = ws.take<uint32_t>(T_max);
+  uint2* coarse = ws.take<uint2>(T_max);
+  uint32_t* bin_cnt = ws.take<uint32_t>(sp.SB + 1);
+  uint32_t* bin_off = ws.take<uint32_t>(sp.SB + 1);
+  uint32_t* tpo = ws.take<uint32_t>(sp.SB + 1);
+  uint32_t* base1 = ws.take<uint32_t>((size_t)sp.chunks1 * sp.W * sp.bins);
+  uint32_t* base2 = ws.take<uint32_t>((size_t)sp.tasks2_max * sp.F);
   uint32_t* sorted = ws.take<uint32_t>(T_max);
   uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
   uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
@@ -566,14 +519,28 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
   ZK_HIP(hipMemsetAsync(len_hist, 0, 2 * (kMaxPieceLen + 1) * 4, st));
   ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
+  ZK_HIP(hipMemsetAsync(bin_cnt, 0, ((size_t)sp.SB + 1) * 4, st));
   const uint32_t nblk = (p.n + 255) / 256;
   if (p.n) {
-    hipLaunchKernelGGL(msm_count_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, counts, rank);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
+    hipLaunchKernelGGL((msm_sort_coarse_kernel<false>), dim3(sp.chunks1, sp.W), dim3(256), 0, st,
+                       (const uint32_t*)digits, sp, bin_cnt, (const uint32_t*)bin_off, base1, coarse);
+  }
+  scan_u32(st, bin_cnt, sp.SB, 0, 0, bin_off, block_sums, misc + 4, nullptr);
+  scan_u32(st, bin_cnt, sp.SB, 1, sp.CH2, tpo, block_sums, misc + 5, nullptr);
+  if (p.n) {
+    hipLaunchKernelGGL((msm_sort_coarse_kernel<true>), dim3(sp.chunks1, sp.W), dim3(256), 0, st,
+                       (const uint32_t*)digits, sp, bin_cnt, (const uint32_t*)bin_off, base1, coarse);
+    hipLaunchKernelGGL((msm_sort_fine_kernel<false>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
+                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, counts,
+                       (const uint32_t*)off0, base2, sorted);
   }
   scan_u32(st, counts, p.TB, 0, 0, off0, block_sums, misc + 0, misc + 1);
   scan_u32(st, counts, p.TB, 1, p.K0, po_a, block_sums, misc + 2, nullptr);
   if (p.n) {
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, off0, rank, sorted);
+    hipLaunchKernelGGL((msm_sort_fine_kernel<true>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
+                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, counts,
+                       (const uint32_t*)off0, base2, sorted);
   }
   uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
   ZK_HIP(hipMemcpyAsync(hb, misc, 16, hipMemcpyDeviceToHost, st));
