@@ -25,6 +25,22 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
 
 
+def pmc_traffic(workload, kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated on this access pattern:
+    profiles/r01_pmc_hbm_traffic.json). None when this workload has not been profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        for name, v in prof["workloads"].get(workload, {}).items():
+            if kernel_substr in name:
+                return v["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def np_scalars(n, seed):
     import numpy as np
     nr = np.random.default_rng(seed)
@@ -226,7 +242,10 @@ def main():
                        "points_per_gpu": n_local, "sharding": "index ranges, all-gather of partial points"},
             "roofline": {"bound": "hbm", "kernel": "msm_accum0_kernel<Fq> (bucket accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload, "msm_accum0_kernel"),
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE, bytes per launch; each base is re-read once per window)",
                          "kernel_ms": k_ms, "msm_device_ms": msm_dev_ms / args.steps,
                          "note": "algorithmic bytes = 96 B/point x points per launch; the kernel is "
                                  "integer-VALU-bound (v_mad_u64_u32), not HBM-bound: see DESIGN.md"},

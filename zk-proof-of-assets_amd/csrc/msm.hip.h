@@ -305,10 +305,15 @@ static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint3
   if (valid) order[base[len] + h[len] + local] = t;
 }
 
+// waves per SIMD the accumulation kernel is compiled for (register budget 512 / waves):
+// G1: 132 VGPRs -> 3 waves (4 waves = 128 VGPRs measured no faster: the kernel is at the ALU ceiling); G2: 256 -> 2
+template <class F> struct AccumWaves { static constexpr int N = 3; };
+template <> struct AccumWaves<Fq2> { static constexpr int N = 2; };
+
 // level 0: items are sorted point indices; piece j of bucket b covers entries
 // [off0[b] + j*K0, min(off0[b] + cnt0[b], +K0)). Threads take pieces in `order` (longest first).
 template <class F>
-static __global__ __launch_bounds__(256) void msm_accum0_kernel(const void* __restrict__ bases,
+static __global__ __launch_bounds__(256, AccumWaves<F>::N) void msm_accum0_kernel(const void* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ cnt0,
                                                          const uint32_t* __restrict__ off0,
