@@ -71,14 +71,20 @@ PROVE_SHAPES = {
 
 
 def bench_prove(args, zk, dist, rank, world, local_rank, dev):
-    """Full Groth16 prove against a key + witness resident in HBM. N>1: whole proofs are independent
-    (the reference runs one prover process per batch, full_workflow.sh:552): replicas, no collective."""
+    """Full Groth16 prove against a key + witness resident in HBM. N>1: the proof's five MSMs are sharded
+    over the ranks (BASELINE.json configs[3..4]); the H-scalar chain is replicated."""
     import torch
     from zkpoa_amd.synthetic import SyntheticCircuit
     k = int(args.workload[len("prove_2p"):])
     m, n_pub, what = PROVE_SHAPES[k]
+    from zkpoa_amd import sharding
     ctx = zk.Context(local_rank)
-    circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010 + rank, witness_like=True)
+    # N > 1: ONE proof sharded over the N GPUs (strong scaling): same circuit on every rank, each rank
+    # owns index range rank/N of the five MSMs; partial points are all-gathered over RCCL and summed.
+    circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True)
+    header = circ.key.header()
+    if world > 1:
+        circ.key.set_shard(rank, world)
 
     def sync():
         torch.cuda.synchronize()
@@ -86,13 +92,19 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_proof():
+        if world == 1:
+            return circ.prove(0, 0)[0]
+        return sharding.sharded_prove(lambda: ctx.prove_partials_device(circ.key, circ.d_witness.data_ptr()),
+                                      header, zk.sum_partials, zk.prove_assemble, 0, 0, dist, dev)
+
     for _ in range(args.warmup):
-        circ.prove(0, 0)
+        one_proof()
     sync()
     t0 = time.perf_counter()
     acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
     for i in range(args.steps):
-        pts, _ = circ.prove(0, 0)
+        pts = one_proof()
         acc["h_chain"] += ctx.last_ms(3)
         acc["msm_phase"] += ctx.last_ms(4)
         acc["prove"] += ctx.last_ms(5)
@@ -112,13 +124,14 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
         alg = 96 * (3 * m - n_pub - 1) + 160 * m + 96 * n + 6 * 64 * n + 76 * ncoef + 96 * n + 128 * n
         sec = elapsed / args.steps
         line = {
-            "metric": "Groth16 proofs/sec", "value": world * args.steps / elapsed, "unit": "proofs/s",
+            "metric": "Groth16 proofs/sec", "value": args.steps / elapsed, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic",
             "config": {"workload": "full Groth16 prove, domain 2^%d, %d wires, %d public (%s); key and witness "
                                    "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
-                       "n_coefs": ncoef, "parallelism": "replicas (one proof per GPU)" if world > 1 else "single GPU"},
+                       "n_coefs": ncoef, "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
+                                       "points; H-scalar chain replicated" % world) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
                          "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,

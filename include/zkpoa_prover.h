@@ -92,6 +92,26 @@ int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d
                        const uint8_t* r_le, const uint8_t* s_le,
                        uint8_t proof_points[256], uint8_t* public_le, unsigned long public_capacity);
 
+/* ---- one proof sharded over several GPUs (BASELINE.json configs[3]) -------------------
+ * The five MSMs shard by contiguous index ranges; one process per GPU owns shard `rank` of `world`:
+ *   zkpoa_zkey_load_shard   uploads only that rank's byte range of zkey sections 5-9 (coefficients and
+ *                           the H-scalar chain are replicated);
+ *   zkpoa_zkey_set_shard    restricts a fully resident key (zkpoa_zkey_load / _load_device) to a shard;
+ *   zkpoa_prove_partials    -> partials = A(64) B1(64) B2(128) C(64) H(64): the shard's five MSM results;
+ *   (the caller all-gathers the 384 bytes over RCCL and sums component-wise: zkpoa_g1_sum / zkpoa_g2_sum)
+ *   zkpoa_prove_assemble    host only: header_points (zkpoa_zkey_header) + summed partials + r, s -> proof.
+ * RCCL has no elliptic-curve reduction operator, so "all-reduce of partial sums" = all-gather + local add. */
+int zkpoa_zkey_load_shard(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                          uint64_t rank, uint64_t world, zkpoa_zkey** zkey);
+int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t world);
+int zkpoa_zkey_header(const zkpoa_zkey* zkey, uint8_t header_points[448]);
+int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer, unsigned long wtns_size,
+                         uint8_t partials[384], uint8_t* public_le, unsigned long public_capacity);
+int zkpoa_prove_partials_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
+                                uint8_t partials[384]);
+int zkpoa_prove_assemble(const uint8_t header_points[448], const uint8_t partial_sums[384],
+                         const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256]);
+
 /* proof_points / public -> JSON text. style 0 = rapidsnark bytes, 1 = snarkjs bytes
  * (SURVEY.md 8a row a11). Size protocol as groth16_prover. */
 int zkpoa_proof_to_json(const uint8_t proof_points[256], int style, char* buffer, unsigned long* size);

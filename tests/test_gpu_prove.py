@@ -212,3 +212,47 @@ def test_synthetic_circuit_prove_known_dlog(ctx, zk, witness_like):
         assert pts0 != pts1
     finally:
         circ.close()
+
+
+# ---- one proof sharded over several ranks: emulated on one GPU -----------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prove_equals_unsharded(ctx, zk, mid_circuit, world):
+    """Shards loaded with zkpoa_zkey_load_shard (each uploads only its byte range of sections 5-9);
+    partials summed component-wise + host assembly == the unsharded proof, bit for bit."""
+    zkey, _, wt, _ = mid_circuit
+    rng = random.Random(9)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    full = ctx.load_zkey(zkey)
+    try:
+        want, pub = ctx.prove(full, wt, r_, s_)
+        header = full.header()
+    finally:
+        full.close()
+    parts = []
+    for rank in range(world):
+        key = ctx.load_zkey_shard(zkey, rank, world)
+        try:
+            p, pub_r = ctx.prove_partials(key, wt)
+            assert pub_r == pub
+            with pytest.raises(zk.ZkpoaError, match="shard"):
+                ctx.prove(key, wt, r_, s_)
+        finally:
+            key.close()
+        parts.append(p)
+    assert zk.prove_assemble(header, zk.sum_partials(parts), r_, s_) == want
+
+
+def test_set_shard_on_resident_key(ctx, zk):
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    circ = SyntheticCircuit(zk, ctx, 14, 15000, n_public=1, seed=5, witness_like=True)
+    try:
+        want, _ = circ.prove(0, 0)
+        header = circ.key.header()
+        parts = []
+        for rank in range(4):
+            circ.key.set_shard(rank, 4)
+            parts.append(ctx.prove_partials_device(circ.key, circ.d_witness.data_ptr()))
+        circ.key.set_shard(0, 1)
+        assert zk.prove_assemble(header, zk.sum_partials(parts), 0, 0) == want
+    finally:
+        circ.close()

@@ -72,3 +72,61 @@ def test_two_rank_sharded_msm_gloo(n):
         assert p.exitcode == 0
     assert len({r[1] for r in results}) == 1          # identical on every rank
     assert results[0][1] == results[0][2]             # equals the unsharded MSM
+
+
+def _prove_worker(rank, world, port, q):
+    """Sharded prove host logic on CPU: each rank's partial MSMs come from the Python oracle on its index
+    ranges; all-gather (gloo) + component-wise sum + zkpoa_prove_assemble must equal the oracle's proof."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    from conftest import golden_case
+    from oracle.py import bn254 as bn
+    from oracle.py import groth16 as g16
+    zk = load_package()
+    from zkpoa_amd import sharding
+    g = golden_case("n128")
+    zkey = g16.read_zkey(g["circuit.zkey"])
+    _, w = g16.read_wtns(g["witness.wtns"])
+    import json
+    rs = json.loads(g["rs.json"])
+    P = g16.h_scalars(zkey, w)
+    m, npub, n = zkey.nVars, zkey.nPublic, zkey.domainSize
+
+    def partials():
+        lo, hi = sharding.shard_range(m, rank, world)
+        clo, chi = sharding.shard_range(m - npub - 1, rank, world)
+        hlo, hhi = sharding.shard_range(n, rank, world)
+        A = bn.msm_naive(zkey.A[lo:hi], w[lo:hi], bn.FQ)
+        B1 = bn.msm_naive(zkey.B1[lo:hi], w[lo:hi], bn.FQ)
+        B2 = bn.msm_naive(zkey.B2[lo:hi], w[lo:hi], bn.FQ2)
+        C = bn.msm_naive(zkey.C[clo:chi], w[npub + 1 + clo:npub + 1 + chi], bn.FQ)
+        H = bn.msm_naive(zkey.H[hlo:hhi], P[hlo:hhi], bn.FQ)
+        return (g16.g1_to_bytes(A) + g16.g1_to_bytes(B1) + g16.g2_to_bytes(B2) + g16.g1_to_bytes(C) +
+                g16.g1_to_bytes(H))
+
+    header = (g16.g1_to_bytes(zkey.alpha1) + g16.g1_to_bytes(zkey.beta1) + g16.g2_to_bytes(zkey.beta2) +
+              g16.g1_to_bytes(zkey.delta1) + g16.g2_to_bytes(zkey.delta2))
+    pts = sharding.sharded_prove(partials, header, zk.sum_partials, zk.prove_assemble, int(rs["r"]), int(rs["s"]), dist)
+    q.put((rank, zk.proof_to_json(pts, "rapidsnark"), g["proof_rapidsnark.json"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_prove_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got, want in results:
+        assert got == want

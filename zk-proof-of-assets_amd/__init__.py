@@ -28,6 +28,8 @@ EXPORTS = [
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
     "zkpoa_zkey_load_device", "zkpoa_prove_device",
+    "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
+    "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_proof_to_json", "zkpoa_public_to_json",
     "zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_ntt", "zkpoa_h_scalars",
     "zkpoa_msm_g1_device", "zkpoa_msm_g2_device", "zkpoa_ntt_device",
@@ -97,6 +99,15 @@ def lib():
             [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
         L.zkpoa_prove_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p,
                                          ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_zkey_load_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_uint64,
+                                            ctypes.c_uint64, c_void_pp]
+        L.zkpoa_zkey_set_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.zkpoa_zkey_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_prove_partials.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_prove_partials_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_prove_assemble.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                           ctypes.c_void_p]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
@@ -239,6 +250,31 @@ class Context:
                     "zkpoa_zkey_load_device")
         return key
 
+    def load_zkey_shard(self, zkey_bytes, rank, world):
+        """Shard `rank` of `world` of a proving key: only that byte range of sections 5-9 is uploaded."""
+        key = ZKey.__new__(ZKey)
+        key._ctx = self
+        key._h = ctypes.c_void_p()
+        p, k = _buf(zkey_bytes)
+        self._check(lib().zkpoa_zkey_load_shard(self._h, p, len(zkey_bytes), rank, world, ctypes.byref(key._h)),
+                    "zkpoa_zkey_load_shard")
+        return key
+
+    def prove_partials(self, zkey, wtns_bytes):
+        """-> (partials[384] = A|B1|B2|C|H MSM results of the key's shard, public bytes)"""
+        pw, kw = _buf(wtns_bytes)
+        parts = ctypes.create_string_buffer(384)
+        npub = zkey.info()[1]
+        pub = ctypes.create_string_buffer(max(1, 32 * npub))
+        self._check(lib().zkpoa_prove_partials(self._h, zkey._h, pw, len(wtns_bytes), parts, pub, 32 * npub),
+                    "zkpoa_prove_partials")
+        return parts.raw, pub.raw[:32 * npub]
+
+    def prove_partials_device(self, zkey, d_witness):
+        parts = ctypes.create_string_buffer(384)
+        self._check(lib().zkpoa_prove_partials_device(self._h, zkey._h, d_witness, parts), "zkpoa_prove_partials_device")
+        return parts.raw
+
     def prove_device(self, zkey, d_witness, r=None, s=None):
         """Prove with the witness already in HBM -> (proof_points[256], public bytes)."""
         rb = None if r is None else int(r).to_bytes(32, "little")
@@ -277,6 +313,17 @@ class ZKey:
         lib().zkpoa_zkey_info(self._h, out)
         return tuple(int(v) for v in out)
 
+    def set_shard(self, rank, world):
+        """Restrict a fully resident key to shard `rank` of `world` (for zkpoa_prove_partials)."""
+        if lib().zkpoa_zkey_set_shard(self._h, rank, world) != PROVER_OK:
+            raise ZkpoaError("zkpoa_zkey_set_shard failed")
+
+    def header(self):
+        """alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128), wire format."""
+        out = ctypes.create_string_buffer(448)
+        lib().zkpoa_zkey_header(self._h, out)
+        return out.raw
+
     def close(self):
         if self._h and self._ctx._h:
             lib().zkpoa_zkey_free(self._ctx._h, self._h)
@@ -309,6 +356,23 @@ def proof_to_json(proof_points, style="rapidsnark"):
 def public_to_json(public_le, style="rapidsnark"):
     p, k = _buf(public_le if len(public_le) else b"\0")
     return _json_call(lib().zkpoa_public_to_json, p, len(public_le) // 32, 0 if style == "rapidsnark" else 1)
+
+
+def prove_assemble(header_points, partial_sums, r=None, s=None):
+    """Host-only randomised assembly: header (448 B) + summed partials (384 B) + r, s -> proof_points[256]."""
+    rb = None if r is None else int(r).to_bytes(32, "little")
+    sb = None if s is None else int(s).to_bytes(32, "little")
+    out = ctypes.create_string_buffer(256)
+    if lib().zkpoa_prove_assemble(bytes(header_points), bytes(partial_sums), rb, sb, out) != PROVER_OK:
+        raise ZkpoaError("zkpoa_prove_assemble failed")
+    return out.raw
+
+
+def sum_partials(partials_list):
+    """Component-wise sum of per-rank partials (each 384 B = A|B1|B2|C|H) -> 384 B."""
+    g1 = lambda lo: g1_sum(b"".join(p[lo:lo + 64] for p in partials_list))
+    b2 = g2_sum(b"".join(p[128:256] for p in partials_list))
+    return g1(0) + g1(64) + b2 + g1(256) + g1(320)
 
 
 def g1_sum(points):

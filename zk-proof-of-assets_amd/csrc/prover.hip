@@ -103,6 +103,24 @@ struct zkpoa_zkey {
   void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
   void* d_witness = nullptr;  // nVars * 32 B
   bool owns_points = true;    // false when the point sections belong to the caller (zkpoa_zkey_load_device)
+  // Shard of the MSMs this handle covers: contiguous global index ranges. The device
+  // buffers dA/dB1/dB2 start at global wire index `wbase`, dC at C-section index `cbase`, dH at `hbase`.
+  uint64_t wlo = 0, wcnt = 0, wbase = 0;   // A, B1, B2: wire indices [wlo, wlo + wcnt)
+  uint64_t clo = 0, ccnt = 0, cbase = 0;   // C: section indices (wire nPublic+1+idx)
+  uint64_t hlo = 0, hcnt = 0, hbase = 0;   // H: domain indices
+  void set_full() {
+    wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
+  }
+  static void split(uint64_t n, uint64_t rank, uint64_t world, uint64_t& lo, uint64_t& cnt) {
+    uint64_t base = n / world, rem = n % world;
+    lo = rank * base + (rank < rem ? rank : rem);
+    cnt = base + (rank < rem ? 1 : 0);
+  }
+  void set_shard(uint64_t rank, uint64_t world) {
+    split(nVars, rank, world, wlo, wcnt);
+    split((uint64_t)nVars - nPublic - 1, rank, world, clo, ccnt);
+    split(domain, rank, world, hlo, hcnt);
+  }
   void release() {
     void* pts[] = {dA, dB1, dB2, dC, dH};
     if (owns_points)
@@ -151,7 +169,8 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs) {
   if (herr) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
 }
 
-zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size) {
+zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
+                           uint64_t world = 1) {
   Sections secs = parse_binfile(buf, size, "zkey", 2);
   const Section& s1 = need(secs, 1, "1 (protocol)");
   if (s1.len < 4 || rd_u32(s1.p) != 1) throw ProverError(PROVER_ERROR, "zkey file is not groth16");
@@ -194,12 +213,18 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
       s9.len != n * 64)
     throw ProverError(PROVER_ERROR, "zkey point section has the wrong size");
 
+  if (world == 0 || rank >= world) throw ProverError(PROVER_ERROR, "zkey shard: rank/world out of range");
+  zk->set_shard(rank, world);   // world == 1: the whole key
+  zk->wbase = zk->wlo;
+  zk->cbase = zk->clo;
+  zk->hbase = zk->hlo;
   try {
-    zk->dA = dev_upload(s5.p, s5.len);
-    zk->dB1 = dev_upload(s6.p, s6.len);
-    zk->dB2 = dev_upload(s7.p, s7.len);
-    zk->dC = dev_upload(s8.p, s8.len);
-    zk->dH = dev_upload(s9.p, s9.len);
+    // each rank uploads only its byte range of every point section
+    zk->dA = dev_upload(s5.p + zk->wlo * 64, zk->wcnt * 64);
+    zk->dB1 = dev_upload(s6.p + zk->wlo * 64, zk->wcnt * 64);
+    zk->dB2 = dev_upload(s7.p + zk->wlo * 128, zk->wcnt * 128);
+    zk->dC = dev_upload(s8.p + zk->clo * 64, zk->ccnt * 64);
+    zk->dH = dev_upload(s9.p + zk->hlo * 64, zk->hcnt * 64);
     hipStream_t st = ctx->dev.lanes[0].stream;
     void* d_recs = dev_upload(s4.p + 4, zk->nCoefs * 44);
     try {
@@ -274,21 +299,26 @@ WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
   return w;
 }
 
-// The witness is already in zk->d_witness (device).
-void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, const uint8_t* s_le,
-                uint8_t proof_points[256]) {
+// Partial MSM results of this handle's shard: A(64) B1(64) B2(128) C(64) H(64). The witness is already
+// in zk->d_witness (device). The H-scalar chain runs in full on every rank (replicated).
+void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) {
   auto t0 = std::chrono::steady_clock::now();
-  uint8_t rb[32], sb[32];
-  if (r_le) memcpy(rb, r_le, 32); else random_scalar(rb);
-  if (s_le) memcpy(sb, s_le, 32); else random_scalar(sb);
   Lane& l0 = ctx->dev.lanes[0];
-
-  // four witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back)
-  uint8_t outA[64], outB1[64], outB2[128], outC[64], outH[64];
+  uint8_t* outA = out;
+  uint8_t* outB1 = out + 64;
+  uint8_t* outB2 = out + 128;
+  uint8_t* outC = out + 256;
+  uint8_t* outH = out + 320;
   std::exception_ptr errs[4];
   float msm_ms[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   const char* wit = reinterpret_cast<const char*>(zk->d_witness);
-  const uint64_t nC = (uint64_t)zk->nVars - zk->nPublic - 1;
+  const char* pA = reinterpret_cast<const char*>(zk->dA) + (zk->wlo - zk->wbase) * 64;
+  const char* pB1 = reinterpret_cast<const char*>(zk->dB1) + (zk->wlo - zk->wbase) * 64;
+  const char* pB2 = reinterpret_cast<const char*>(zk->dB2) + (zk->wlo - zk->wbase) * 128;
+  const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
+  const char* pH = reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
+  const char* witW = wit + zk->wlo * 32;
+  const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
   auto guarded = [&](int slot, std::function<void()> fn) {
     return std::thread([&, slot, fn] {
       try {
@@ -299,20 +329,18 @@ void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, c
       }
     });
   };
-  auto tm0 = std::chrono::steady_clock::now();
-  std::thread tA = guarded(0, [&] { msm_run_g1(ctx, 1, zk->dA, wit, zk->nVars, outA, msm_ms[1]); });
-  std::thread tB1 = guarded(1, [&] { msm_run_g1(ctx, 2, zk->dB1, wit, zk->nVars, outB1, msm_ms[2]); });
-  std::thread tB2 = guarded(2, [&] { msm_run_g2(ctx, 3, zk->dB2, wit, zk->nVars, outB2, msm_ms[3]); });
-  std::thread tC = guarded(3, [&] {
-    msm_run_g1(ctx, 4, zk->dC, wit + (size_t)(zk->nPublic + 1) * 32, nC, outC, msm_ms[4]);
-  });
+  // four witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back)
+  std::thread tA = guarded(0, [&] { msm_run_g1(ctx, 1, pA, witW, zk->wcnt, outA, msm_ms[1]); });
+  std::thread tB1 = guarded(1, [&] { msm_run_g1(ctx, 2, pB1, witW, zk->wcnt, outB1, msm_ms[2]); });
+  std::thread tB2 = guarded(2, [&] { msm_run_g2(ctx, 3, pB2, witW, zk->wcnt, outB2, msm_ms[3]); });
+  std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
 
   std::exception_ptr main_err;
   try {
     ZK_HIP(hipEventRecord(ctx->ev_a[5], l0.stream));
     h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_witness, zk->domain, zk->power, zk->d_abc);
     ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
-    msm_run_g1(ctx, 0, zk->dH, zk->d_abc, zk->domain, outH, msm_ms[0]);
+    msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0]);
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
   } catch (...) {
     main_err = std::current_exception();
@@ -324,28 +352,42 @@ void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, c
   if (main_err) std::rethrow_exception(main_err);
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
-  auto tm1 = std::chrono::steady_clock::now();
+  auto t1 = std::chrono::steady_clock::now();
+  ctx->ms[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  ctx->ms[0] = msm_ms[0][0];
+  ctx->ms[1] = msm_ms[0][1];
+}
 
-  // randomised assembly (groth16_prove.js tail)
+// header: alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128); sums: A B1 B2 C H summed over all shards.
+// Randomised assembly (groth16_prove.js tail). Host only.
+void prove_assemble(const uint8_t header[448], const uint8_t sums[384], const uint8_t* r_le, const uint8_t* s_le,
+                    uint8_t proof_points[256]) {
+  uint8_t rb[32], sb[32];
+  if (r_le) memcpy(rb, r_le, 32); else random_scalar(rb);
+  if (s_le) memcpy(sb, s_le, 32); else random_scalar(sb);
+  Affine<HFq> alpha1 = h_affine_from_bytes<HFq>(header), beta1 = h_affine_from_bytes<HFq>(header + 64);
+  Affine<HFq2> beta2 = h_affine_from_bytes<HFq2>(header + 128);
+  Affine<HFq> delta1 = h_affine_from_bytes<HFq>(header + 256);
+  Affine<HFq2> delta2 = h_affine_from_bytes<HFq2>(header + 320);
   uint64_t rk[4], sk[4], nrs[4];
   memcpy(rk, rb, 32);
   memcpy(sk, sb, 32);
   HFr rs = hfr_from_le(rb).to_mont() * hfr_from_le(sb).to_mont();
   rs.neg().from_mont().to_bytes(nrs);
 
-  XYZZ<HFq> d1 = XYZZ<HFq>::from_affine(zk->delta1);
-  XYZZ<HFq2> d2 = XYZZ<HFq2>::from_affine(zk->delta2);
-  XYZZ<HFq> pi_a = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outA));
-  xyzz_add_affine(pi_a, zk->alpha1, false);
+  XYZZ<HFq> d1 = XYZZ<HFq>::from_affine(delta1);
+  XYZZ<HFq2> d2 = XYZZ<HFq2>::from_affine(delta2);
+  XYZZ<HFq> pi_a = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(sums));
+  xyzz_add_affine(pi_a, alpha1, false);
   xyzz_add(pi_a, h_mul(d1, rk));
-  XYZZ<HFq2> pi_b = XYZZ<HFq2>::from_affine(h_affine_from_bytes<HFq2>(outB2));
-  xyzz_add_affine(pi_b, zk->beta2, false);
+  XYZZ<HFq2> pi_b = XYZZ<HFq2>::from_affine(h_affine_from_bytes<HFq2>(sums + 128));
+  xyzz_add_affine(pi_b, beta2, false);
   xyzz_add(pi_b, h_mul(d2, sk));
-  XYZZ<HFq> pib1 = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outB1));
-  xyzz_add_affine(pib1, zk->beta1, false);
+  XYZZ<HFq> pib1 = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(sums + 64));
+  xyzz_add_affine(pib1, beta1, false);
   xyzz_add(pib1, h_mul(d1, sk));
-  XYZZ<HFq> pi_c = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(outC));
-  xyzz_add_affine(pi_c, h_affine_from_bytes<HFq>(outH), false);
+  XYZZ<HFq> pi_c = XYZZ<HFq>::from_affine(h_affine_from_bytes<HFq>(sums + 256));
+  xyzz_add_affine(pi_c, h_affine_from_bytes<HFq>(sums + 320), false);
   xyzz_add(pi_c, h_mul(pi_a, sk));
   xyzz_add(pi_c, h_mul(pib1, rk));
   xyzz_add(pi_c, h_mul(d1, nrs));
@@ -353,12 +395,32 @@ void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, c
   h_affine_to_bytes<HFq>(h_to_affine(pi_a), proof_points);
   h_affine_to_bytes<HFq2>(h_to_affine(pi_b), proof_points + 64);
   h_affine_to_bytes<HFq>(h_to_affine(pi_c), proof_points + 192);
+}
 
-  auto t1 = std::chrono::steady_clock::now();
-  ctx->ms[4] = std::chrono::duration<float, std::milli>(tm1 - tm0).count();
-  ctx->ms[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  ctx->ms[0] = msm_ms[0][0];
-  ctx->ms[1] = msm_ms[0][1];
+void zkey_header_bytes(const zkpoa_zkey* zk, uint8_t out[448]) {
+  h_affine_to_bytes<HFq>(zk->alpha1, out);
+  h_affine_to_bytes<HFq>(zk->beta1, out + 64);
+  h_affine_to_bytes<HFq2>(zk->beta2, out + 128);
+  h_affine_to_bytes<HFq>(zk->delta1, out + 256);
+  h_affine_to_bytes<HFq2>(zk->delta2, out + 320);
+}
+
+bool is_full_key(const zkpoa_zkey* zk) {
+  return zk->wlo == 0 && zk->wcnt == zk->nVars && zk->clo == 0 && zk->ccnt == (uint64_t)zk->nVars - zk->nPublic - 1 &&
+         zk->hlo == 0 && zk->hcnt == zk->domain;
+}
+
+// unsharded prove = partials of the whole key + assembly
+void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, const uint8_t* s_le,
+                uint8_t proof_points[256]) {
+  auto t0 = std::chrono::steady_clock::now();
+  if (!is_full_key(zk))
+    throw ProverError(PROVER_ERROR, "this key handle is a shard: use zkpoa_prove_partials + zkpoa_prove_assemble");
+  uint8_t parts[384], header[448];
+  prove_partials(ctx, zk, parts);
+  zkey_header_bytes(zk, header);
+  prove_assemble(header, parts, r_le, s_le, proof_points);
+  ctx->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
@@ -553,6 +615,80 @@ extern "C" int zkpoa_zkey_load(zkpoa_context* ctx, const void* zkey_buffer, unsi
   return PROVER_OK;
 }
 
+extern "C" int zkpoa_zkey_load_shard(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                                     uint64_t rank, uint64_t world, zkpoa_zkey** out) {
+  if (!ctx || !out || !zkey_buffer) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size, rank, world);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t world) {
+  if (!zkey || world == 0 || rank >= world) return PROVER_ERROR;
+  if (zkey->wbase || zkey->cbase || zkey->hbase) return PROVER_ERROR;  // only a fully resident key can be re-sharded
+  zkey->set_shard(rank, world);
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_header(const zkpoa_zkey* zkey, uint8_t header_points[448]) {
+  if (!zkey || !header_points) return PROVER_ERROR;
+  zkey_header_bytes(zkey, header_points);
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer,
+                                    unsigned long wtns_size, uint8_t partials[384], uint8_t* public_le,
+                                    unsigned long public_capacity) {
+  if (!ctx || !zkey || !wtns_buffer || !partials) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    WtnsView w = parse_wtns(reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size);
+    if (w.n != zkey->nVars)
+      throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " +
+                                                           std::to_string(zkey->nVars) + ", witness: " + std::to_string(w.n));
+    if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
+      throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    ZK_HIP(hipMemcpyAsync(zkey->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    prove_partials(ctx, zkey, partials);
+    if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_prove_partials_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
+                                           uint8_t partials[384]) {
+  if (!ctx || !zkey || !d_witness || !partials) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    if (d_witness != zkey->d_witness) {
+      ZK_HIP(hipMemcpyAsync(zkey->d_witness, d_witness, (size_t)zkey->nVars * 32, hipMemcpyDeviceToDevice, st));
+      ZK_HIP(hipStreamSynchronize(st));
+    }
+    prove_partials(ctx, zkey, partials);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_prove_assemble(const uint8_t header_points[448], const uint8_t partial_sums[384],
+                                    const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256]) {
+  if (!header_points || !partial_sums || !proof_points) return PROVER_ERROR;
+  try {
+    prove_assemble(header_points, partial_sums, r_le, s_le, proof_points);
+  } catch (const std::exception&) {
+    return PROVER_ERROR;
+  }
+  return PROVER_OK;
+}
+
 extern "C" void zkpoa_zkey_free(zkpoa_context* ctx, zkpoa_zkey* zkey) {
   if (!zkey) return;
   if (ctx) {
@@ -613,6 +749,7 @@ extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint6
     zk->beta2 = h_affine_from_bytes<HFq2>(header_points + 128);
     zk->delta1 = h_affine_from_bytes<HFq>(header_points + 256);
     zk->delta2 = h_affine_from_bytes<HFq2>(header_points + 320);
+    zk->set_full();
     build_csr(ctx, zk.get(), d_coef_records);
     ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power);
     ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));

@@ -42,3 +42,11 @@ def sharded_msm(compute_partial, group_sum, n, dist=None, device=None):
     lo, hi = shard_range(n, rank, world)
     part = compute_partial(lo, hi)
     return combine_partials(group_sum, all_gather_bytes(part, dist, device))
+
+
+def sharded_prove(compute_partials, header_points, sum_partials, assemble, r, s, dist=None, device=None):
+    """One Groth16 proof over `world` GPUs: compute_partials() -> this rank's 384-byte partial MSM results
+    (A|B1|B2|C|H of its shard); all-gather; component-wise sum; host-side assembly with the SAME r, s on
+    every rank (the caller fixes them, e.g. rank 0 draws and broadcasts). Returns proof_points[256]."""
+    parts = all_gather_bytes(compute_partials(), dist, device)
+    return assemble(header_points, sum_partials(parts), r, s)
