@@ -99,15 +99,20 @@ static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__
       uint32_t j = mb & (half - 1u);
       uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
       uint32_t i0 = (m0 << logT) + c, i1 = i0 + (half << logT);
-      Fr tw = load_field<Fr>(reinterpret_cast<const char*>(small_tw) + 32 * (size_t)(j << (B - 1u - sl)));
       Fr u = lds_load(lds, i0), v = lds_load(lds, i1);
-      if (DIF) {
-        lds_store(lds, i0, u + v);
-        lds_store(lds, i1, (u - v) * tw);
-      } else {
-        v = v * tw;
+      if (sl == 0u) {  // tile-local stage 0: every twiddle is W^0 = 1, no multiplication (uniform branch)
         lds_store(lds, i0, u + v);
         lds_store(lds, i1, u - v);
+      } else {
+        Fr tw = load_field<Fr>(reinterpret_cast<const char*>(small_tw) + 32 * (size_t)(j << (B - 1u - sl)));
+        if (DIF) {
+          lds_store(lds, i0, u + v);
+          lds_store(lds, i1, (u - v) * tw);
+        } else {
+          v = v * tw;
+          lds_store(lds, i0, u + v);
+          lds_store(lds, i1, u - v);
+        }
       }
     }
     __syncthreads();
