@@ -134,6 +134,12 @@ int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned long coeffs
 int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t out[64]);
 int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t out[128]);
 int zkpoa_ntt_device(zkpoa_context* ctx, void* d_data, unsigned log_n, int inverse);
+/* G1 MSM on an explicit lane (0..5: an independent HIP stream + workspace each): lets a caller keep
+ * several MSMs in flight from several host threads, as zkpoa_prove does internally with its five MSMs.
+ * Calls on the same lane must not overlap. zkpoa_last_ms_lane: id 0 = whole MSM, 1 = accumulation kernel. */
+int zkpoa_msm_g1_device_lane(zkpoa_context* ctx, int lane, const void* d_bases, const void* d_scalars, uint64_t n,
+                             uint8_t out[64]);
+float zkpoa_last_ms_lane(const zkpoa_context* ctx, int lane, int id);
 
 /* Synthetic bases for benchmarks at sizes where no CPU generator is affordable:
  * P_i = (a + i*b) * G, i in [i0, i0+n), written affine/Montgomery into d_out (n*64 or n*128 B).

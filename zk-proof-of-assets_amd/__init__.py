@@ -33,6 +33,7 @@ EXPORTS = [
     "zkpoa_proof_to_json", "zkpoa_public_to_json",
     "zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_ntt", "zkpoa_h_scalars",
     "zkpoa_msm_g1_device", "zkpoa_msm_g2_device", "zkpoa_ntt_device",
+    "zkpoa_msm_g1_device_lane", "zkpoa_last_ms_lane",
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
@@ -74,6 +75,10 @@ def lib():
         for name in ("zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_msm_g1_device", "zkpoa_msm_g2_device"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                          ctypes.c_void_p]
+        L.zkpoa_msm_g1_device_lane.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_uint64, ctypes.c_void_p]
+        L.zkpoa_last_ms_lane.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.zkpoa_last_ms_lane.restype = ctypes.c_float
         L.zkpoa_ntt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
         L.zkpoa_ntt_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
         L.zkpoa_h_scalars.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p,
@@ -198,6 +203,16 @@ class Context:
         out = ctypes.create_string_buffer(64)
         self._check(lib().zkpoa_msm_g1_device(self._h, d_bases, d_scalars, n, out), "zkpoa_msm_g1_device")
         return out.raw
+
+    def msm_g1_device_lane(self, lane, d_bases, d_scalars, n):
+        """G1 MSM on lane `lane` (own stream + workspace); thread-safe across different lanes."""
+        out = ctypes.create_string_buffer(64)
+        if lib().zkpoa_msm_g1_device_lane(self._h, lane, d_bases, d_scalars, n, out) != PROVER_OK:
+            raise ZkpoaError("zkpoa_msm_g1_device_lane failed")
+        return out.raw
+
+    def last_ms_lane(self, lane, ident):
+        return float(lib().zkpoa_last_ms_lane(self._h, lane, ident))
 
     def msm_g2_device(self, d_bases, d_scalars, n):
         out = ctypes.create_string_buffer(128)

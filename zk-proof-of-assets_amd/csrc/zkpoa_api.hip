@@ -80,6 +80,26 @@ extern "C" int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, cons
   msm_run_g1(ctx, 0, d_bases, d_scalars, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
+// Same MSM on an explicit lane (stream + workspace), so a caller can keep several MSMs in flight from
+// several host threads: each lane is independent; calls on the SAME lane must not overlap.
+extern "C" int zkpoa_msm_g1_device_lane(zkpoa_context* ctx, int lane, const void* d_bases, const void* d_scalars,
+                                        uint64_t n, uint8_t out[64]) {
+  if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    check_n(n);
+    msm_run_g1(ctx, lane, d_bases, d_scalars, n, out, ctx->lane_ms[lane]);
+  } catch (const std::exception& e) {
+    return PROVER_ERROR;   // last_error is not touched: it is shared between lanes
+  }
+  return PROVER_OK;
+}
+
+extern "C" float zkpoa_last_ms_lane(const zkpoa_context* ctx, int lane, int id) {
+  if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes || id < 0 || id > 1) return -1.f;
+  return ctx->lane_ms[lane][id];
+}
+
 extern "C" int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n,
                                    uint8_t out[128]) {
   ZK_API_BEGIN(ctx)

@@ -16,6 +16,7 @@ struct zkpoa_context {
   zkpoa::NttEngine* ntt = nullptr;
   std::string last_error;
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float lane_ms[zkpoa::DeviceCtx::kLanes][2] = {};   // per-lane {whole MSM, accumulation kernel} of the last MSM
   int opt_msm_c = 0;
   hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
   hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
