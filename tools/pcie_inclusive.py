@@ -1,0 +1,63 @@
+"""PCIe-inclusive timings for DESIGN.md: host-buffer MSM, zkey load + prove from a file image, prover CLI.
+(bench.py's `value` is measured with inputs resident in HBM; these are the rates a caller handing over
+host buffers / files sees.)"""
+import os, struct, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from __graft_entry__ import load_package
+z = load_package()
+from zkpoa_amd.synthetic import SyntheticCircuit, R_MOD, Q_MOD
+ctx = z.Context(0)
+
+# 1. host-buffer G1 MSM, 2^20
+n = 1 << 20
+d_bases = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+ctx.gen_bases_g1_device(12345, 67890, 0, n, d_bases.data_ptr())
+bases = d_bases.cpu().numpy().tobytes()
+nr = np.random.default_rng(1)
+limbs = nr.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64); limbs[:, 3] &= np.uint64((1 << 59) - 1)
+scal = limbs.tobytes()
+ctx.msm_g1(bases, scal, n)
+t0 = time.perf_counter()
+for _ in range(5): ctx.msm_g1(bases, scal, n)
+t = (time.perf_counter() - t0) / 5
+print("host-buffer zkpoa_msm_g1 2^20 (96 MiB upload per call, via ctypes copies): %.2f ms/MSM = %.1f M pts/s" % (t * 1e3, n / t / 1e6))
+
+# 2. zkey file image at the layer_one(2) shape -> load + prove, and the CLI
+k, m, npub = 21, 2083343, 1
+circ = SyntheticCircuit(z, ctx, k, m, n_public=npub, seed=7, witness_like=True)
+def le32(x): return int(x).to_bytes(32, "little")
+hdr = circ.key.header()
+sec2 = struct.pack("<I", 32) + le32(Q_MOD) + struct.pack("<I", 32) + le32(R_MOD) + struct.pack("<III", m, npub, 1 << k)
+sec2 += hdr[0:64] + hdr[64:128] + hdr[128:256] + hdr[128:256] + hdr[256:320] + hdr[320:448]   # gamma2 := beta2 (unused by prove)
+secs = [(1, struct.pack("<I", 1)), (2, sec2), (3, bytes(64 * (npub + 1))), (4, circ.coeff_section_bytes()),
+        (5, circ.d_A.cpu().numpy().tobytes()), (6, circ.d_B1.cpu().numpy().tobytes()),
+        (7, circ.d_B2.cpu().numpy().tobytes()), (8, circ.d_C.cpu().numpy().tobytes()[:64 * (m - npub - 1)]),
+        (9, circ.d_H.cpu().numpy().tobytes()), (10, bytes(68))]
+img = bytearray(b"zkey" + struct.pack("<II", 1, len(secs)))
+for sid, payload in secs:
+    img += struct.pack("<IQ", sid, len(payload)); img += payload
+img = bytes(img)
+wt = (b"wtns" + struct.pack("<II", 2, 2) + struct.pack("<IQ", 1, 40) + struct.pack("<I", 32) + le32(R_MOD) +
+      struct.pack("<I", m) + struct.pack("<IQ", 2, 32 * m) + circ.witness_bytes())
+want, _ = circ.prove(0, 0)
+circ.close()
+print("zkey image %.2f GB, wtns %.1f MB" % (len(img) / 1e9, len(wt) / 1e6))
+t0 = time.perf_counter(); key = ctx.load_zkey(img); tl = time.perf_counter() - t0
+t0 = time.perf_counter(); pts, pub = ctx.prove(key, wt, 0, 0); tp1 = time.perf_counter() - t0
+t0 = time.perf_counter(); pts, pub = ctx.prove(key, wt, 0, 0); tp = time.perf_counter() - t0
+key.close()
+assert pts == want
+print("zkpoa_zkey_load (parse + upload + CSR build): %.3f s = %.2f GB/s; zkpoa_prove incl. witness upload: first %.1f ms, steady %.1f ms"
+      % (tl, len(img) / tl / 1e9, tp1 * 1e3, tp * 1e3))
+d = tempfile.mkdtemp()
+open(d + "/c.zkey", "wb").write(img); open(d + "/w.wtns", "wb").write(wt)
+env = dict(os.environ, ZKPOA_R="0", ZKPOA_S="0", ZKPOA_VERBOSE="1")
+for i in range(2):
+    t0 = time.perf_counter()
+    rc = subprocess.run([z.PROVER_BIN, d + "/c.zkey", d + "/w.wtns", d + "/proof.json", d + "/public.json"], env=env, capture_output=True, text=True)
+    tc = time.perf_counter() - t0
+    print("prover CLI run %d (page-cached zkey file, process start + HIP init + mmap + upload + prove + JSON): %.2f s  rc=%d  %s" % (i, tc, rc.returncode, rc.stderr.strip().splitlines()[-1] if rc.stderr.strip() else ""))
+assert open(d + "/proof.json").read() == z.proof_to_json(want)
+print("CLI proof.json matches the resident-key proof")
