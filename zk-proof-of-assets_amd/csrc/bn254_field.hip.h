@@ -21,6 +21,9 @@ struct FqParams {
   // q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
   static constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                                     0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  // 2q (elements are kept lazily in [0, 2q): 4q < 2^256)
+  static constexpr uint32_t P2[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
+                                     0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
   static constexpr uint32_t INV = 0xe4866389u;  // -q^-1 mod 2^32
   // R mod q
   static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
@@ -34,6 +37,8 @@ struct FrParams {
   // r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
   static constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
                                     0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t P2[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
+                                     0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};
   static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
   static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
                                       0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
@@ -86,26 +91,38 @@ struct Fp {
     for (int i = 0; i < 8; i++) r.l[i] = PRM::R2[i];
     return r;
   }
-  ZK_DEV bool is_zero() const {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= l[i];
-    return o == 0;
-  }
-  ZK_DEV bool operator==(const Fp& b) const {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= (l[i] ^ b.l[i]);
-    return o == 0;
-  }
-  ZK_DEV bool operator!=(const Fp& b) const { return !(*this == b); }
-
-  // r = (a >= p) ? a - p : a     (a < 2p)
-  static ZK_DEV Fp reduce_once(const Fp& a) {
+  // Lazy reduction: every value of this class lies in [0, 2p) (4p < 2^256 for both BN254 primes), so the
+  // Montgomery product needs no final conditional subtraction: (a*b + m*p)/R < 2p whenever a, b < 2p.
+  // Values are brought to the canonical range [0, p) only where representation matters: stores,
+  // comparisons, bit scans (canon()).
+  ZK_DEV Fp canon() const {  // [0, 2p) -> [0, p)
     Fp d;
     uint32_t bw = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) d.l[i] = subb(a.l[i], PRM::P[i], bw);
+    for (int i = 0; i < 8; i++) d.l[i] = subb(l[i], PRM::P[i], bw);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = bw ? l[i] : d.l[i];
+    return r;
+  }
+  ZK_DEV bool is_zero() const {  // value == 0 mod p, i.e. representation 0 or p
+    uint32_t o = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      o |= l[i];
+      e |= (l[i] ^ PRM::P[i]);
+    }
+    return o == 0 || e == 0;
+  }
+  ZK_DEV bool operator==(const Fp& b) const { return (*this - b).is_zero(); }
+  ZK_DEV bool operator!=(const Fp& b) const { return !(*this == b); }
+
+  // r = (a >= 2p) ? a - 2p : a     (a < 4p)
+  static ZK_DEV Fp reduce_2p(const Fp& a) {
+    Fp d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.l[i] = subb(a.l[i], PRM::P2[i], bw);
     Fp r;
 #pragma unroll
     for (int i = 0; i < 8; i++) r.l[i] = bw ? a.l[i] : d.l[i];
@@ -117,8 +134,8 @@ struct Fp {
     uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s.l[i] = addc(a.l[i], b.l[i], c);
-    // p < 2^254 so a+b < 2^255: no carry out of the top limb
-    return reduce_once(s);
+    // a + b < 4p < 2^256: no carry out of the top limb
+    return reduce_2p(s);
   }
   friend ZK_DEV Fp operator-(const Fp& a, const Fp& b) {
     Fp d;
@@ -129,15 +146,18 @@ struct Fp {
     uint32_t c = 0;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = addc(d.l[i], PRM::P[i] & mask, c);
+    for (int i = 0; i < 8; i++) r.l[i] = addc(d.l[i], PRM::P2[i] & mask, c);
     return r;
   }
-  ZK_DEV Fp neg() const {
-    if (is_zero()) return *this;
+  ZK_DEV Fp neg() const {  // 2p - a, except 0 -> 0 (keeps the result below 2p)
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i];
+    if (o == 0) return *this;
     Fp r;
     uint32_t bw = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = subb(PRM::P[i], l[i], bw);
+    for (int i = 0; i < 8; i++) r.l[i] = subb(PRM::P2[i], l[i], bw);
     return r;
   }
   ZK_DEV Fp dbl() const { return *this + *this; }
@@ -169,7 +189,7 @@ struct Fp {
       lo = (lo >> 32) | ((uint64_t)hi << 32);
       hi = 0;
     }
-    return reduce_once(r);
+    return r;  // < 2p (lazy reduction)
   }
   ZK_DEV Fp sqr() const { return (*this) * (*this); }
 
@@ -255,7 +275,8 @@ ZK_DEV Fp<PRM> load_fp(const void* p) {
   return r;
 }
 template <class PRM>
-ZK_DEV void store_fp(void* p, const Fp<PRM>& v) {
+ZK_DEV void store_fp(void* p, const Fp<PRM>& vin) {  // memory always holds the canonical value
+  const Fp<PRM> v = vin.canon();
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gen_bases_kernel(Affine<F> G, Affine<F> B
   im.l[0] = (uint32_t)idx;
   im.l[1] = (uint32_t)(idx >> 32);
   im = im.to_mont();
-  Fr s = (a_m + b_m * im).from_mont();
+  Fr s = (a_m + b_m * im).from_mont().canon();  // canonical: the bits are scanned below
   XYZZ<F> acc = XYZZ<F>::inf();
   for (int limb = 7; limb >= 0; limb--) {
     uint32_t w = s.l[limb];
