@@ -57,8 +57,10 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   void* pinned = nullptr;
   size_t pinned_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  void init() {
-    ZK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  void init(bool high_priority = false) {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, high_priority ? hi : lo));
     pinned_cap = 1 << 20;
     ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev0));
@@ -96,7 +98,8 @@ struct DeviceCtx {
     hipDeviceProp_t prop;
     ZK_HIP(hipGetDeviceProperties(&prop, dev));
     num_cu = prop.multiProcessorCount;
-    for (auto& l : lanes) l.init();
+    // lane 0 carries the prover's critical path (H-scalar chain -> H MSM): highest stream priority
+    for (int i = 0; i < kLanes; i++) lanes[i].init(i == 0);
     ok = true;
   }
   void destroy() {
