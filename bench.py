@@ -89,7 +89,7 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     def one_proof():
@@ -140,7 +140,7 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     circ.close()
     ctx.close()
@@ -173,9 +173,11 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the hot path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("ZKPOA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload.startswith("prove_2p"):
         return bench_prove(args, zk, dist, rank, world, local_rank, dev)
@@ -211,7 +213,7 @@ def main():
         return part, ctx.last_ms_lane(lane, 1), ctx.last_ms_lane(lane, 0)
 
     def combine(part):
-        if world == 1:
+        if world == 1 and not force_dist:
             return part
         return sharding.combine_partials(zk.g1_sum, sharding.all_gather_bytes(part, dist, dev))
 
@@ -230,8 +232,8 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if world > 1 or force_dist:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     run(max(args.warmup, inflight))      # also sizes every lane's workspace outside the timed region
@@ -241,14 +243,14 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     pool.shutdown()
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- correctness of what was timed (outside the timed region): known-dlog check
     d_loc = dlog_expected(limbs, a, b, i0)
-    if world > 1:
+    if world > 1 or force_dist:
         parts = [None] * world
         dist.all_gather_object(parts, d_loc)
         d_all = sum(parts) % R_MOD
@@ -305,8 +307,8 @@ def main():
                                               "(oracle/c, Pippenger threaded by window)" % sample_log,
                                     "seconds": tcpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if world > 1 or force_dist:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     ctx.close()
 

@@ -57,10 +57,12 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   void* pinned = nullptr;
   size_t pinned_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  void init(bool high_priority = false) {
+  // level 2 = highest, 1 = middle, 0 = lowest stream priority
+  void init(int level = 0) {
     int lo = 0, hi = 0;  // numerically lower = higher priority
     ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, high_priority ? hi : lo));
+    int prio = level >= 2 ? hi : (level == 1 ? (lo + hi) / 2 : lo);
+    ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio));
     pinned_cap = 1 << 20;
     ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
     ZK_HIP(hipEventCreate(&ev0));
@@ -99,7 +101,8 @@ struct DeviceCtx {
     ZK_HIP(hipGetDeviceProperties(&prop, dev));
     num_cu = prop.multiProcessorCount;
     // lane 0 carries the prover's critical path (H-scalar chain -> H MSM): highest stream priority
-    for (int i = 0; i < kLanes; i++) lanes[i].init(i == 0);
+    // and lane 3 (the G2 MSM, the longest of the witness MSMs) the middle one.
+    for (int i = 0; i < kLanes; i++) lanes[i].init(i == 0 ? 2 : (i == 3 ? 1 : 0));
     ok = true;
   }
   void destroy() {

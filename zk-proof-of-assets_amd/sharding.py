@@ -19,7 +19,7 @@ def shard_range(n, rank, world):
 def all_gather_bytes(payload, dist=None, device=None):
     """All-gather a fixed-size byte string over the default process group; returns the list by rank."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [bytes(payload)]
     t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
     if device is not None:
