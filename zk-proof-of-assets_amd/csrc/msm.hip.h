@@ -443,56 +443,86 @@ struct MsmSizes {
   static constexpr size_t kXyzz = 4 * FieldBytes<F>::N;
 };
 
-// bytes of workspace an MSM of n points needs (upper bound)
+// ---- host driver: two phases ---------------------------------------------------------------------
+// Phase A (scalars only): digits, bucket sort, scans, piece ordering. Its result can serve several
+// accumulations over DIFFERENT base arrays with the SAME scalars -- the prover's A, B1 and B2 queries all
+// use the witness -- so those three MSMs sort once.
+// Phase B (bases): bucket accumulation, further levels, bucket reduction, window sums to the host.
+struct MsmSorted {
+  MsmPlan p;
+  uint32_t* counts = nullptr;   // entries per bucket
+  uint32_t* off0 = nullptr;     // bucket offsets into `sorted`
+  uint32_t* po_a = nullptr;     // level-0 piece offsets
+  uint32_t* sorted = nullptr;   // point index | sign << 31, grouped by bucket
+  uint32_t* order = nullptr;    // piece ids, longest first
+  uint32_t* pbkt = nullptr;     // piece -> bucket
+  uint32_t total1 = 0;          // level-0 pieces
+  uint32_t max_count = 0;       // largest bucket
+};
+
+inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+
+inline size_t msm_sort_workspace_bytes(const MsmPlan& p) {
+  size_t T = (size_t)p.n * p.W;
+  size_t p1 = T / p.K0 + p.TB + 1;
+  SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  size_t bytes = 0;
+  bytes += al256((size_t)p.TB * 4);                  // counts
+  bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // off0, po_a
+  bytes += al256(T * 4) * 2;                         // digits, sorted
+  bytes += al256(T * 8);                             // coarse-sorted entries
+  bytes += al256(((size_t)sp.SB + 1) * 4) * 3;       // bin_cnt, bin_off, tpo
+  bytes += al256((size_t)sp.chunks1 * sp.W * sp.bins * 4);
+  bytes += al256((size_t)sp.tasks2_max * sp.F * 4);
+  bytes += al256(((size_t)p.TB / kScanTile + 2) * 4);
+  bytes += al256(64);
+  bytes += al256(p1 * 4) * 3;                        // pbkt, plen, order
+  bytes += al256((kMaxPieceLen + 1) * 4 * 2);        // len_hist, cursor
+  return bytes + (1 << 12);
+}
+
 template <class F>
-inline size_t msm_workspace_bytes(const MsmPlan& p) {
+inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
   size_t T = (size_t)p.n * p.W;
   size_t p1 = T / p.K0 + p.TB + 1;
   size_t p2 = p1 / 2 + 1;
   size_t segs = p.TB / MsmPlan::SEG;
   size_t bytes = 0;
-  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-  bytes += al((size_t)p.TB * 4) * 2;        // counts, (spare)
-  bytes += al(((size_t)p.TB + 1) * 4) * 4;  // off0, po_a, po_b, po_c
-  SortPlan sp = make_sort_plan(p.n, p.W, p.c);
-  bytes += al(T * 4) * 2;                   // digits, sorted
-  bytes += al(T * 8);                       // coarse-sorted entries
-  bytes += al(((size_t)sp.SB + 1) * 4) * 3; // bin_cnt, bin_off, tpo
-  bytes += al((size_t)sp.chunks1 * sp.W * sp.bins * 4);
-  bytes += al((size_t)sp.tasks2_max * sp.F * 4);
-  bytes += al(((size_t)p.TB / kScanTile + 2) * 4);
-  bytes += al(64);
-  bytes += al(p1 * 4) * 3;                  // pbkt, plen, order
-  bytes += al((kMaxPieceLen + 1) * 4 * 2);  // len_hist, cursor
-  bytes += al((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
-  bytes += al(p1 * MsmSizes<F>::kXyzz);            // P1
-  bytes += al(p2 * MsmSizes<F>::kXyzz);            // P2
-  bytes += al(segs * MsmSizes<F>::kXyzz);          // X
-  bytes += al((segs / 256 + p.W) * MsmSizes<F>::kXyzz) * 2;
-  return bytes + (1 << 16);
+  bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // po_b, po_c
+  bytes += al256(((size_t)p.TB / kScanTile + 2) * 4);
+  bytes += al256(64);
+  bytes += al256((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
+  bytes += al256(p1 * MsmSizes<F>::kXyzz);            // P1
+  bytes += al256(p2 * MsmSizes<F>::kXyzz);            // P2
+  bytes += al256(segs * MsmSizes<F>::kXyzz);          // X
+  bytes += al256((segs / 256 + p.W) * MsmSizes<F>::kXyzz) * 2;
+  return bytes + (1 << 12);
 }
 
-// Runs the device part of one MSM on lane.stream. d_bases / d_scalars are device pointers.
-// On return (stream synchronised) window_sums (host, W * XYZZ bytes, Montgomery) hold the per-window
-// sums sum_b b*B[w][b]; the caller combines them (host Horner). Returns the plan used.
-template <class F>
-inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
-                          int force_c = 0, float* accum_ms = nullptr) {
-  MsmPlan p = msm_make_plan(n, force_c);
-  hipStream_t st = lane.stream;
-  size_t need = msm_workspace_bytes<F>(p);
+inline void lane_reserve(Lane& lane, size_t need) {
   if (lane.ws.cap < need) {
-    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipStreamSynchronize(lane.stream));
     lane.ws.reserve(need);
   }
+}
+
+// Phase A on lane.stream. `extra_bytes` is reserved on top (for a following phase B on the same lane).
+// The arena is reset here; the result stays valid until the lane's next msm_sort_phase. With
+// sync_at_end the stream is synchronised on return, so other lanes may read the result.
+inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int force_c,
+                                size_t (*extra)(const MsmPlan&), bool sync_at_end = false) {
+  MsmSorted sr;
+  sr.p = msm_make_plan(n, force_c);
+  const MsmPlan& p = sr.p;
+  hipStream_t st = lane.stream;
+  lane_reserve(lane, msm_sort_workspace_bytes(p) + (extra ? extra(p) : 0));
   Arena& ws = lane.ws;
   ws.reset();
   const size_t T_max = (size_t)p.n * p.W;
-  uint32_t* counts = ws.take<uint32_t>(p.TB);
-  uint32_t* off0 = ws.take<uint32_t>(p.TB + 1);
-  uint32_t* po_a = ws.take<uint32_t>(p.TB + 1);
-  uint32_t* po_b = ws.take<uint32_t>(p.TB + 1);
   const SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  sr.counts = ws.take<uint32_t>(p.TB);
+  sr.off0 = ws.take<uint32_t>(p.TB + 1);
+  sr.po_a = ws.take<uint32_t>(p.TB + 1);
   uint32_t* digits = ws.take<uint32_t>(T_max);
   uint2* coarse = ws.take<uint2>(T_max);
   uint32_t* bin_cnt = ws.take<uint32_t>(sp.SB + 1);
@@ -500,30 +530,19 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   uint32_t* tpo = ws.take<uint32_t>(sp.SB + 1);
   uint32_t* base1 = ws.take<uint32_t>((size_t)sp.chunks1 * sp.W * sp.bins);
   uint32_t* base2 = ws.take<uint32_t>((size_t)sp.tasks2_max * sp.F);
-  uint32_t* sorted = ws.take<uint32_t>(T_max);
+  sr.sorted = ws.take<uint32_t>(T_max);
   uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
   uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
-  char* buckets = ws.take<char>((size_t)p.TB * MsmSizes<F>::kXyzz);
   size_t p1_cap = T_max / p.K0 + p.TB + 1;
-  size_t p2_cap = p1_cap / 2 + 1;
-  uint32_t* pbkt = ws.take<uint32_t>(p1_cap);
+  sr.pbkt = ws.take<uint32_t>(p1_cap);
   uint32_t* plen = ws.take<uint32_t>(p1_cap);
-  uint32_t* order = ws.take<uint32_t>(p1_cap);
+  sr.order = ws.take<uint32_t>(p1_cap);
   uint32_t* len_hist = ws.take<uint32_t>(2 * (kMaxPieceLen + 1));
   uint32_t* len_cursor = len_hist + (kMaxPieceLen + 1);
-  char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
-  char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
-  const uint32_t segs = p.TB / MsmPlan::SEG;
-  const uint32_t S0 = p.Nb / MsmPlan::SEG;
-  char* X = ws.take<char>((size_t)segs * MsmSizes<F>::kXyzz);
-  const uint32_t S1 = (S0 + 255) / 256;
-  char* Y1 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
-  char* Y2 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
 
-  ZK_HIP(hipMemsetAsync(counts, 0, (size_t)p.TB * 4, st));
+  ZK_HIP(hipMemsetAsync(sr.counts, 0, (size_t)p.TB * 4, st));
   ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
   ZK_HIP(hipMemsetAsync(len_hist, 0, 2 * (kMaxPieceLen + 1) * 4, st));
-  ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
   ZK_HIP(hipMemsetAsync(bin_cnt, 0, ((size_t)sp.SB + 1) * 4, st));
   const uint32_t nblk = (p.n + 255) / 256;
   if (p.n) {
@@ -537,37 +556,77 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
     hipLaunchKernelGGL((msm_sort_coarse_kernel<true>), dim3(sp.chunks1, sp.W), dim3(256), 0, st,
                        (const uint32_t*)digits, sp, bin_cnt, (const uint32_t*)bin_off, base1, coarse);
     hipLaunchKernelGGL((msm_sort_fine_kernel<false>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
-                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, counts,
-                       (const uint32_t*)off0, base2, sorted);
+                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, sr.counts,
+                       (const uint32_t*)sr.off0, base2, sr.sorted);
   }
-  scan_u32(st, counts, p.TB, 0, 0, off0, block_sums, misc + 0, misc + 1);
-  scan_u32(st, counts, p.TB, 1, p.K0, po_a, block_sums, misc + 2, nullptr);
+  scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
+  scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
   if (p.n) {
     hipLaunchKernelGGL((msm_sort_fine_kernel<true>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
-                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, counts,
-                       (const uint32_t*)off0, base2, sorted);
+                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, sr.counts,
+                       (const uint32_t*)sr.off0, base2, sr.sorted);
   }
   uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
   ZK_HIP(hipMemcpyAsync(hb, misc, 16, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
-  const uint32_t max_count = hb[1];
-  const uint32_t total1 = hb[2];
-  if (accum_ms && !total1) ZK_HIP(hipEventRecord(lane.ev0, st));
-  if (total1) {
-    const uint32_t pgrid = (total1 + 255) / 256;
-    hipLaunchKernelGGL(msm_piece_len_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)counts,
-                       (const uint32_t*)po_a, p.TB, p.K0, pbkt, plen, len_hist);
+  sr.max_count = hb[1];
+  sr.total1 = hb[2];
+  if (sr.total1) {
+    const uint32_t pgrid = (sr.total1 + 255) / 256;
+    hipLaunchKernelGGL(msm_piece_len_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)sr.counts,
+                       (const uint32_t*)sr.po_a, p.TB, p.K0, sr.pbkt, plen, len_hist);
     hipLaunchKernelGGL(msm_piece_order_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)plen,
-                       (const uint32_t*)po_a, p.TB, (const uint32_t*)len_hist, len_cursor, order);
-    if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
-    hipLaunchKernelGGL((msm_accum0_kernel<F>), dim3(pgrid), dim3(256), 0, st, d_bases, sorted, counts, off0, po_a,
-                       (const uint32_t*)order, (const uint32_t*)pbkt, p.TB, p.K0, (void*)buckets, (void*)P1);
+                       (const uint32_t*)sr.po_a, p.TB, (const uint32_t*)len_hist, len_cursor, sr.order);
+  }
+  if (sync_at_end) ZK_HIP(hipStreamSynchronize(st));  // other lanes are about to read the result
+  return sr;
+}
+
+// Phase B on lane.stream for base array d_bases. `own_arena`: true when `sr` was produced on this lane
+// by the immediately preceding msm_sort_phase (the accumulation buffers are then taken after it);
+// false when `sr` lives on another lane (that lane's stream must have finished phase A): this lane's arena
+// is reset and only holds the accumulation buffers. On return window_sums_host = W XYZZ window sums.
+template <class F>
+inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases, void* window_sums_host,
+                            bool own_arena, float* accum_ms = nullptr) {
+  const MsmPlan& p = sr.p;
+  hipStream_t st = lane.stream;
+  Arena& ws = lane.ws;
+  if (!own_arena) {
+    lane_reserve(lane, msm_accum_workspace_bytes<F>(p));
+    ws.reset();
+  }
+  const size_t T_max = (size_t)p.n * p.W;
+  uint32_t* po_b = ws.take<uint32_t>(p.TB + 1);
+  uint32_t* po_c = ws.take<uint32_t>(p.TB + 1);
+  uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
+  uint32_t* misc = ws.take<uint32_t>(16);
+  char* buckets = ws.take<char>((size_t)p.TB * MsmSizes<F>::kXyzz);
+  size_t p1_cap = T_max / p.K0 + p.TB + 1;
+  size_t p2_cap = p1_cap / 2 + 1;
+  char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
+  char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
+  const uint32_t segs = p.TB / MsmPlan::SEG;
+  const uint32_t S0 = p.Nb / MsmPlan::SEG;
+  char* X = ws.take<char>((size_t)segs * MsmSizes<F>::kXyzz);
+  const uint32_t S1 = (S0 + 255) / 256;
+  char* Y1 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
+  char* Y2 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
+
+  ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
+  if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
+  if (sr.total1) {
+    const uint32_t pgrid = (sr.total1 + 255) / 256;
+    hipLaunchKernelGGL((msm_accum0_kernel<F>), dim3(pgrid), dim3(256), 0, st, d_bases, (const uint32_t*)sr.sorted,
+                       (const uint32_t*)sr.counts, (const uint32_t*)sr.off0, (const uint32_t*)sr.po_a,
+                       (const uint32_t*)sr.order, (const uint32_t*)sr.pbkt, p.TB, p.K0, (void*)buckets, (void*)P1);
   }
   if (accum_ms) ZK_HIP(hipEventRecord(lane.ev1, st));
-  // further levels while some bucket still has more than one partial sum
-  uint64_t max_items = ((uint64_t)max_count + p.K0 - 1) / p.K0;  // max items per bucket entering level 1
-  uint64_t total_in = total1;                                      // upper bound of items entering the level
-  uint32_t* po_in = po_a;
+  // further levels while some bucket still has more than one partial sum; the shared po_a is read-only,
+  // the level offsets ping-pong between this phase's own po_b / po_c
+  uint64_t max_items = ((uint64_t)sr.max_count + p.K0 - 1) / p.K0;  // max items per bucket entering level 1
+  uint64_t total_in = sr.total1;                                       // upper bound of items entering the level
+  const uint32_t* po_in = sr.po_a;
   uint32_t* po_out = po_b;
   char* Pin = P1;
   char* Pout = P2;
@@ -577,10 +636,11 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
     if (bound > cap_out) throw HipError("msm: level buffer too small");
     scan_u32(st, po_in, p.TB, 3, p.K, po_out, block_sums, misc + 3, nullptr);
     hipLaunchKernelGGL((msm_accumN_kernel<F>), dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, st, (const void*)Pin,
-                       po_in, po_out, p.TB, p.K, (void*)buckets, (void*)Pout);
+                       po_in, (const uint32_t*)po_out, p.TB, p.K, (void*)buckets, (void*)Pout);
     max_items = (max_items + p.K - 1) / p.K;
     total_in = bound;
-    std::swap(po_in, po_out);
+    po_in = po_out;
+    po_out = (po_out == po_b) ? po_c : po_b;
     std::swap(Pin, Pout);
     std::swap(cap_in, cap_out);
   }
@@ -593,7 +653,6 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   int yi = 0;
   while (true) {
     uint32_t S_out = (S + 255) / 256;
-    // Y1 holds up to S1*W entries, Y2 up to W*ceil(S1/256) <= Y1's size as well when S1 > 256: size both by S1*W
     hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, p.W), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
                        (const void*)cur, S, S_out, (void*)ybuf[yi]);
     cur = ybuf[yi];
@@ -606,7 +665,15 @@ inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars
   ZK_HIP(hipGetLastError());
   memcpy(window_sums_host, lane.pinned, (size_t)p.W * MsmSizes<F>::kXyzz);
   if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));
-  return p;
+}
+
+// One complete MSM on one lane (phase A + phase B). Returns the plan used.
+template <class F>
+inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
+                          int force_c = 0, float* accum_ms = nullptr) {
+  MsmSorted sr = msm_sort_phase(lane, d_scalars, n, force_c, &msm_accum_workspace_bytes<F>);
+  msm_accum_phase<F>(lane, sr, d_bases, window_sums_host, true, accum_ms);
+  return sr.p;
 }
 
 }  // namespace zkpoa

@@ -6,4 +6,8 @@ void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void
                 float* ms2) {
   msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out, ms2);
 }
+void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
+                  uint8_t* out, float* ms2) {
+  msm_accum_run<Fq2, HFq2>(ctx, lane_id, *sr, own_arena, d_bases, out, ms2);
+}
 }  // namespace zkpoa

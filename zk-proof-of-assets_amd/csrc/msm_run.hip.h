@@ -25,4 +25,26 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }
 
+
+// Phase B only, for a sort result that may live on another lane (prover: A, B1, B2 share the witness sort).
+template <class F, class HF>
+void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool own_arena, const void* d_bases,
+                   uint8_t* out, float* ms2) {
+  Lane& lane = ctx->dev.lanes[lane_id];
+  std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
+  float acc_ms = 0;
+  ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
+  msm_accum_phase<F>(lane, sr, d_bases, wsums.data(), own_arena, &acc_ms);
+  ZK_HIP(hipEventRecord(ctx->ev_b[lane_id], lane.stream));
+  ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));
+  float tot = 0;
+  ZK_HIP(hipEventElapsedTime(&tot, ctx->ev_a[lane_id], ctx->ev_b[lane_id]));
+  if (ms2) {
+    ms2[0] = tot;
+    ms2[1] = acc_ms;
+  }
+  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.W, sr.p.c);
+  h_affine_to_bytes<HF>(h_to_affine(r), out);
+}
+
 }  // namespace zkpoa

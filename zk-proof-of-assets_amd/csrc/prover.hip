@@ -19,6 +19,7 @@
 #include <chrono>
 #include <exception>
 #include <functional>
+#include <future>
 #include <memory>
 #include <map>
 #include <mutex>
@@ -329,10 +330,24 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       }
     });
   };
-  // four witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back)
-  std::thread tA = guarded(0, [&] { msm_run_g1(ctx, 1, pA, witW, zk->wcnt, outA, msm_ms[1]); });
-  std::thread tB1 = guarded(1, [&] { msm_run_g1(ctx, 2, pB1, witW, zk->wcnt, outB1, msm_ms[2]); });
-  std::thread tB2 = guarded(2, [&] { msm_run_g2(ctx, 3, pB2, witW, zk->wcnt, outB2, msm_ms[3]); });
+  // Witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back). A, B1 and B2 use
+  // the same scalars (the shard's witness range), so their bucket sort runs once (lane 1) and the three
+  // accumulations read it; C (different range) sorts on its own.
+  std::promise<const MsmSorted*> sorted_promise;
+  std::shared_future<const MsmSorted*> sorted_ready = sorted_promise.get_future().share();
+  std::thread tA = guarded(0, [&] {
+    MsmSorted* sr = nullptr;
+    try {
+      sr = msm_sort_run(ctx, 1, witW, zk->wcnt);
+      sorted_promise.set_value(sr);
+    } catch (...) {
+      sorted_promise.set_exception(std::current_exception());
+      throw;
+    }
+    msm_accum_g1(ctx, 1, sr, true, pA, outA, msm_ms[1]);
+  });
+  std::thread tB1 = guarded(1, [&] { msm_accum_g1(ctx, 2, sorted_ready.get(), false, pB1, outB1, msm_ms[2]); });
+  std::thread tB2 = guarded(2, [&] { msm_accum_g2(ctx, 3, sorted_ready.get(), false, pB2, outB2, msm_ms[3]); });
   std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
 
   std::exception_ptr main_err;
@@ -349,6 +364,10 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   tB1.join();
   tB2.join();
   tC.join();
+  try {
+    msm_sorted_free(const_cast<MsmSorted*>(sorted_ready.get()));
+  } catch (...) {
+  }
   if (main_err) std::rethrow_exception(main_err);
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);

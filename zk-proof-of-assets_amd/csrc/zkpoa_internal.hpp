@@ -45,6 +45,15 @@ void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* ou
 void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
 void gen_bases_g2(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
+// shared-sort form (prover: the A, B1 and B2 queries use the same witness scalars): sort once on `lane`
+// (stream synchronised on return), then accumulate each base array on its own lane.
+struct MsmSorted;
+MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n);  // delete with msm_sorted_free
+void msm_sorted_free(MsmSorted* sr);
+void msm_accum_g1(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
+                  uint8_t* out, float* ms2);
+void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
+                  uint8_t* out, float* ms2);
 // ntt.hip
 void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k);  // builds twiddle tables (hipMalloc) once per k
 void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k);
