@@ -158,6 +158,18 @@ int zkpoa_g2_sum(const void* points, uint64_t count, uint8_t out[128]);
 int zkpoa_g1_mul(const uint8_t point[64], const uint8_t scalar_le[32], uint8_t out[64]);
 int zkpoa_g2_mul(const uint8_t point[128], const uint8_t scalar_le[32], uint8_t out[128]);
 
+/* ---- the step after the path; host only, no GPU ----------------------------------------
+ * zkpoa_groth16_verify: `npx snarkjs groth16 verify <vkey> <public> <proof>` (scripts/g16_verify.sh:213-216)
+ *   on the three JSON texts. Returns PROVER_OK (valid), ZKPOA_VERIFY_INVALID_PROOF, or PROVER_ERROR (malformed).
+ * zkpoa_sanitize_proof: `python scripts/sanitize_groth16_proof.py` (sanitize_groth16_proof.py:39-124): the
+ *   text of sanitized_proof.json (43-bit x 6 limbs; e(-alpha1, beta2) as negalfa1xbeta2), byte-identical to the
+ *   reference's output. Size protocol as groth16_prover. */
+#define ZKPOA_VERIFY_INVALID_PROOF 0x10
+int zkpoa_groth16_verify(const char* vkey_json, const char* public_json, const char* proof_json,
+                         char* error_msg, unsigned long error_msg_maxsize);
+int zkpoa_sanitize_proof(const char* vkey_json, const char* public_json, const char* proof_json,
+                         char* buffer, unsigned long* size, char* error_msg, unsigned long error_msg_maxsize);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Timings (ms, HIP events on the stream that ran the kernels) of the last call on this context.
  * id: 0 = whole device part of last MSM, 1 = its bucket-accumulation kernel (dominant kernel),

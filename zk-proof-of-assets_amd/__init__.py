@@ -37,6 +37,7 @@ EXPORTS = [
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
+    "zkpoa_groth16_verify", "zkpoa_sanitize_proof",
 ]
 
 
@@ -113,6 +114,10 @@ def lib():
         L.zkpoa_prove_partials_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.zkpoa_prove_assemble.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                            ctypes.c_void_p]
+        L.zkpoa_groth16_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p,
+                                           ctypes.c_ulong]
+        L.zkpoa_sanitize_proof.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ul_p,
+                                           ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
@@ -371,6 +376,37 @@ def proof_to_json(proof_points, style="rapidsnark"):
 def public_to_json(public_le, style="rapidsnark"):
     p, k = _buf(public_le if len(public_le) else b"\0")
     return _json_call(lib().zkpoa_public_to_json, p, len(public_le) // 32, 0 if style == "rapidsnark" else 1)
+
+
+VERIFY_BIN = os.path.join(_HERE, "zkpoa-verify")
+SANITIZE_BIN = os.path.join(_HERE, "zkpoa-sanitize")
+
+
+def groth16_verify(vkey_json, public_json, proof_json):
+    """`snarkjs groth16 verify` on the three JSON texts (host only) -> True / False; raises on malformed input."""
+    err = ctypes.create_string_buffer(512)
+    rc = lib().zkpoa_groth16_verify(vkey_json.encode(), public_json.encode(), proof_json.encode(), err, 512)
+    if rc == PROVER_OK:
+        return True
+    if rc == 0x10:
+        return False
+    raise ZkpoaError("zkpoa_groth16_verify: " + err.value.decode())
+
+
+def sanitize_proof(vkey_json, public_json, proof_json):
+    """The text sanitize_groth16_proof.py writes to sanitized_proof.json (host only)."""
+    err = ctypes.create_string_buffer(512)
+    size = ctypes.c_ulong(1 << 16)
+    buf = ctypes.create_string_buffer(size.value)
+    rc = lib().zkpoa_sanitize_proof(vkey_json.encode(), public_json.encode(), proof_json.encode(), buf,
+                                    ctypes.byref(size), err, 512)
+    if rc == PROVER_ERROR_SHORT_BUFFER:
+        buf = ctypes.create_string_buffer(size.value)
+        rc = lib().zkpoa_sanitize_proof(vkey_json.encode(), public_json.encode(), proof_json.encode(), buf,
+                                        ctypes.byref(size), err, 512)
+    if rc != PROVER_OK:
+        raise ZkpoaError("zkpoa_sanitize_proof: " + err.value.decode())
+    return buf.value.decode()
 
 
 def prove_assemble(header_points, partial_sums, r=None, s=None):

@@ -1,0 +1,298 @@
+// Groth16 verification and proof sanitising on the host: what the reference runs
+// right after every prove -- `npx snarkjs groth16 verify <vkey> <public> <proof>`
+// (scripts/g16_verify.sh:213-216) and `python sanitize_groth16_proof.py <proof_dir>`
+// (scripts/sanitize_groth16_proof.py:39-124, 43-bit x 6 limbs per scripts/lib/field_helper.py) --
+// as two C-ABI entry points over pairing.hpp. No GPU is needed or used: a verification is three
+// Miller loops and one final exponentiation (~15 ms on one core).
+#include "pairing.hpp"
+#include "zkpoa_internal.hpp"
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace zkpoa;
+using namespace zkpoa::pairing;
+
+namespace {
+
+// ---- a minimal JSON reader (objects, arrays, strings, bare numbers) -------------------------------------
+struct JVal {
+  enum Kind { OBJ, ARR, STR, NUM } kind = NUM;
+  std::string text;                                    // STR / NUM
+  std::vector<JVal> items;                             // ARR
+  std::vector<std::pair<std::string, JVal>> members;   // OBJ
+  const JVal& at(const std::string& key) const {
+    for (const auto& m : members)
+      if (m.first == key) return m.second;
+    throw std::runtime_error("JSON: missing key \"" + key + "\"");
+  }
+  const JVal& operator[](size_t i) const {
+    if (kind != ARR || i >= items.size()) throw std::runtime_error("JSON: array index out of range");
+    return items[i];
+  }
+  const std::string& scalar() const {
+    if (kind != STR && kind != NUM) throw std::runtime_error("JSON: expected a number or string");
+    return text;
+  }
+};
+
+struct JParser {
+  const char* p;
+  explicit JParser(const char* s) : p(s) {}
+  void ws() {
+    while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') p++;
+  }
+  JVal parse() {
+    ws();
+    JVal v;
+    if (*p == '{') {
+      v.kind = JVal::OBJ;
+      p++;
+      ws();
+      if (*p == '}') { p++; return v; }
+      while (true) {
+        ws();
+        JVal k = parse();
+        if (k.kind != JVal::STR) throw std::runtime_error("JSON: object key is not a string");
+        ws();
+        if (*p != ':') throw std::runtime_error("JSON: expected ':'");
+        p++;
+        v.members.emplace_back(k.text, parse());
+        ws();
+        if (*p == ',') { p++; continue; }
+        if (*p == '}') { p++; break; }
+        throw std::runtime_error("JSON: expected ',' or '}'");
+      }
+    } else if (*p == '[') {
+      v.kind = JVal::ARR;
+      p++;
+      ws();
+      if (*p == ']') { p++; return v; }
+      while (true) {
+        v.items.push_back(parse());
+        ws();
+        if (*p == ',') { p++; continue; }
+        if (*p == ']') { p++; break; }
+        throw std::runtime_error("JSON: expected ',' or ']'");
+      }
+    } else if (*p == '"') {
+      v.kind = JVal::STR;
+      p++;
+      while (*p && *p != '"') {
+        if (*p == '\\' && p[1]) p++;
+        v.text.push_back(*p++);
+      }
+      if (*p != '"') throw std::runtime_error("JSON: unterminated string");
+      p++;
+    } else {
+      v.kind = JVal::NUM;
+      while (*p && *p != ',' && *p != ']' && *p != '}' && *p != ' ' && *p != '\n' && *p != '\t' && *p != '\r')
+        v.text.push_back(*p++);
+      if (v.text.empty()) throw std::runtime_error("JSON: unexpected character");
+    }
+    return v;
+  }
+};
+
+JVal parse_json(const char* s) {
+  if (!s) throw std::runtime_error("JSON: null input");
+  JParser jp(s);
+  JVal v = jp.parse();
+  jp.ws();
+  if (*jp.p) throw std::runtime_error("JSON: trailing characters");
+  return v;
+}
+
+// ---- decimal <-> field ----------------------------------------------------------------------------------
+// decimal string -> 256-bit integer (false if not decimal or >= 2^256)
+bool parse_u256(const std::string& s, uint64_t out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (s.empty()) return false;
+  for (char ch : s) {
+    if (ch < '0' || ch > '9') return false;
+    u128 carry = (unsigned)(ch - '0');
+    for (int i = 0; i < 4; i++) {
+      u128 cur = (u128)out[i] * 10 + carry;
+      out[i] = (uint64_t)cur;
+      carry = cur >> 64;
+    }
+    if (carry) return false;
+  }
+  return true;
+}
+bool lt_modulus(const uint64_t v[4], const uint64_t p[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (v[i] < p[i]) return true;
+    if (v[i] > p[i]) return false;
+  }
+  return false;
+}
+HFq fq_from_dec(const std::string& s) {
+  uint64_t v[4];
+  if (!parse_u256(s, v) || !lt_modulus(v, HFqParams::P)) throw std::runtime_error("coordinate is not a field element: " + s);
+  HFq r{{v[0], v[1], v[2], v[3]}};
+  return r.to_mont();
+}
+HFq2 fq2_from_json(const JVal& v) { return HFq2{fq_from_dec(v[0].scalar()), fq_from_dec(v[1].scalar())}; }
+
+// projective JSON forms: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]]; affine = (x/z, y/z) as in the reference's
+// sanitizer (scripts/sanitize_groth16_proof.py:44-59); z = 0 -> infinity
+G1 g1_from_json(const JVal& v) {
+  HFq x = fq_from_dec(v[0].scalar()), y = fq_from_dec(v[1].scalar()), z = fq_from_dec(v[2].scalar());
+  if (z.is_zero()) return {HFq::zero(), HFq::zero()};
+  HFq zi = z.inv();
+  return {x * zi, y * zi};
+}
+G2 g2_from_json(const JVal& v) {
+  HFq2 x = fq2_from_json(v[0]), y = fq2_from_json(v[1]), z = fq2_from_json(v[2]);
+  if (z.is_zero()) return {HFq2::zero(), HFq2::zero()};
+  HFq2 zi = z.inv();
+  return {x * zi, y * zi};
+}
+G1 g1_neg(const G1& p) { return {p.x, p.y.neg()}; }
+
+struct VKey {
+  G1 alpha1;
+  G2 beta2, gamma2, delta2;
+  std::vector<G1> IC;
+  size_t nPublic = 0;
+};
+VKey vkey_from_json(const JVal& v) {
+  VKey k;
+  k.alpha1 = g1_from_json(v.at("vk_alpha_1"));
+  k.beta2 = g2_from_json(v.at("vk_beta_2"));
+  k.gamma2 = g2_from_json(v.at("vk_gamma_2"));
+  k.delta2 = g2_from_json(v.at("vk_delta_2"));
+  const JVal& ic = v.at("IC");
+  for (const auto& p : ic.items) k.IC.push_back(g1_from_json(p));
+  k.nPublic = (size_t)std::stoull(v.at("nPublic").scalar());
+  if (k.IC.size() != k.nPublic + 1) throw std::runtime_error("vkey: IC length does not match nPublic");
+  return k;
+}
+
+struct Proof {
+  G1 a, c;
+  G2 b;
+};
+Proof proof_from_json(const JVal& v) { return {g1_from_json(v.at("pi_a")), g1_from_json(v.at("pi_c")), g2_from_json(v.at("pi_b"))}; }
+
+G1 g1_add_mul(const G1& acc, const G1& p, const uint64_t k[4]) {
+  XYZZ<HFq> r = XYZZ<HFq>::from_affine(acc);
+  xyzz_add(r, h_mul(XYZZ<HFq>::from_affine(p), k));
+  return h_to_affine(r);
+}
+
+// snarkjs groth16 verify: public inputs in the field, proof points on their curves,
+// e(-A, B) * e(alpha, beta) * e(vk_x, gamma) * e(C, delta) == 1
+bool verify_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
+  VKey vk = vkey_from_json(vkj);
+  Proof pr = proof_from_json(prj);
+  if (pubj.kind != JVal::ARR || pubj.items.size() != vk.nPublic) return false;
+  if (!g1_on_curve(pr.a) || !g1_on_curve(pr.c) || !g2_on_curve(pr.b)) return false;
+  G1 vkx = vk.IC[0];
+  for (size_t i = 0; i < vk.nPublic; i++) {
+    uint64_t s[4];
+    if (!parse_u256(pubj[i].scalar(), s) || !lt_modulus(s, HFrParams::P)) return false;
+    vkx = g1_add_mul(vkx, vk.IC[i + 1], s);
+  }
+  Fq12 f = miller_loop(pr.b, g1_neg(pr.a));
+  f = f * miller_loop(vk.beta2, vk.alpha1);
+  f = f * miller_loop(vk.gamma2, vkx);
+  f = f * miller_loop(vk.delta2, pr.c);
+  return final_exponentiation(f).is_one();
+}
+
+// ---- sanitizer: 43-bit x 6 limb arrays, Python json.dump formatting ----------------------------------------
+std::string u64_dec(uint64_t v) { return std::to_string(v); }
+std::string limbs43(const HFq& x) {  // numberToArray(x, 43, 6)
+  HFq s = x.from_mont();
+  u128 lo = ((u128)s.l[1] << 64) | s.l[0], hi = ((u128)s.l[3] << 64) | s.l[2];
+  std::string out = "[";
+  for (int i = 0; i < 6; i++) {
+    uint64_t limb = (uint64_t)(lo & (((u128)1 << 43) - 1));
+    out += u64_dec(limb);
+    if (i < 5) out += ", ";
+    lo = (lo >> 43) | (hi << (128 - 43));
+    hi >>= 43;
+  }
+  return out + "]";
+}
+std::string fq2_limbs(const HFq2& x) { return "[" + limbs43(x.c0) + ", " + limbs43(x.c1) + "]"; }
+std::string g2_limbs(const G2& p) { return "[" + fq2_limbs(p.x) + ", " + fq2_limbs(p.y) + "]"; }
+std::string g1_limbs(const G1& p) { return "[" + limbs43(p.x) + ", " + limbs43(p.y) + "]"; }
+
+std::string sanitize_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
+  VKey vk = vkey_from_json(vkj);
+  Proof pr = proof_from_json(prj);
+  Fq12 nab = pairing::pairing(vk.beta2, g1_neg(vk.alpha1));   // pairing(beta, negalpha)
+  HFq2 co[6];
+  nab.fq2_coeffs(co);
+  std::string o = "{\"gamma2\": " + g2_limbs(vk.gamma2) + ", \"delta2\": " + g2_limbs(vk.delta2) + ", \"negalfa1xbeta2\": [";
+  for (int i = 0; i < 6; i++) o += fq2_limbs(co[i]) + (i < 5 ? ", " : "");
+  o += "], \"IC\": [";
+  for (size_t i = 0; i < vk.IC.size(); i++) o += g1_limbs(vk.IC[i]) + (i + 1 < vk.IC.size() ? ", " : "");
+  o += "], \"negpa\": " + g1_limbs(g1_neg(pr.a)) + ", \"pb\": " + g2_limbs(pr.b) + ", \"pc\": " + g1_limbs(pr.c);
+  o += ", \"pubInput\": [";
+  if (pubj.kind != JVal::ARR) throw std::runtime_error("public.json is not an array");
+  for (size_t i = 0; i < pubj.items.size(); i++) {
+    uint64_t s[4];
+    if (!parse_u256(pubj[i].scalar(), s)) throw std::runtime_error("public input is not a decimal integer");
+    // int(pubInput): re-emit the canonical decimal (strips leading zeros like Python's int())
+    HFr t{{s[0], s[1], s[2], s[3]}};
+    std::string dec;
+    {  // decimal of a raw 256-bit integer
+      uint64_t v[4] = {s[0], s[1], s[2], s[3]};
+      std::string rev;
+      while (v[0] | v[1] | v[2] | v[3]) {
+        u128 rem = 0;
+        for (int k = 3; k >= 0; k--) {
+          u128 cur = (rem << 64) | v[k];
+          v[k] = (uint64_t)(cur / 10);
+          rem = cur % 10;
+        }
+        rev.push_back((char)('0' + (int)rem));
+      }
+      dec = rev.empty() ? "0" : std::string(rev.rbegin(), rev.rend());
+    }
+    (void)t;
+    o += dec + (i + 1 < pubj.items.size() ? ", " : "");
+  }
+  o += "]}";
+  return o;
+}
+
+}  // namespace
+
+extern "C" int zkpoa_groth16_verify(const char* vkey_json, const char* public_json, const char* proof_json,
+                                    char* error_msg, unsigned long error_msg_maxsize) {
+  try {
+    JVal vk = parse_json(vkey_json), pub = parse_json(public_json), pr = parse_json(proof_json);
+    return verify_impl(vk, pub, pr) ? PROVER_OK : ZKPOA_VERIFY_INVALID_PROOF;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+}
+
+extern "C" int zkpoa_sanitize_proof(const char* vkey_json, const char* public_json, const char* proof_json,
+                                    char* buffer, unsigned long* size, char* error_msg,
+                                    unsigned long error_msg_maxsize) {
+  if (!size) return PROVER_ERROR;
+  try {
+    JVal vk = parse_json(vkey_json), pub = parse_json(public_json), pr = parse_json(proof_json);
+    std::string s = sanitize_impl(vk, pub, pr);
+    unsigned long needed = (unsigned long)s.size() + 1;
+    if (!buffer || *size < needed) {
+      *size = needed;
+      return PROVER_ERROR_SHORT_BUFFER;
+    }
+    memcpy(buffer, s.c_str(), needed);
+    *size = needed;
+    return PROVER_OK;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+}
