@@ -58,6 +58,6 @@ for i in range(2):
     t0 = time.perf_counter()
     rc = subprocess.run([z.PROVER_BIN, d + "/c.zkey", d + "/w.wtns", d + "/proof.json", d + "/public.json"], env=env, capture_output=True, text=True)
     tc = time.perf_counter() - t0
-    print("prover CLI run %d (page-cached zkey file, process start + HIP init + mmap + upload + prove + JSON): %.2f s  rc=%d  %s" % (i, tc, rc.returncode, rc.stderr.strip().splitlines()[-1] if rc.stderr.strip() else ""))
+    print("prover CLI run %d (page-cached zkey file, process start + HIP init + mmap + upload + prove + JSON): %.2f s  rc=%d  %s" % (i, tc, rc.returncode, " || ".join(rc.stderr.strip().splitlines())))
 assert open(d + "/proof.json").read() == z.proof_to_json(want)
 print("CLI proof.json matches the resident-key proof")

@@ -82,10 +82,15 @@ const uint8_t kQ[32] = {0x47, 0xfd, 0x7c, 0xd8, 0x16, 0x8c, 0x20, 0x3c, 0x8d, 0x
 const uint8_t kR[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
                         0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
 
-void* dev_upload(const void* src, size_t bytes) {
+void* dev_upload(zkpoa_context* ctx, const void* src, size_t bytes) {
   void* d = nullptr;
   ZK_HIP(hipMalloc(&d, bytes ? bytes : 1));
-  if (bytes) ZK_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+  try {
+    if (bytes) ctx->uploader.upload(d, src, bytes, ctx->dev.device);
+  } catch (...) {
+    (void)hipFree(d);
+    throw;
+  }
   return d;
 }
 
@@ -221,13 +226,13 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
   zk->hbase = zk->hlo;
   try {
     // each rank uploads only its byte range of every point section
-    zk->dA = dev_upload(s5.p + zk->wlo * 64, zk->wcnt * 64);
-    zk->dB1 = dev_upload(s6.p + zk->wlo * 64, zk->wcnt * 64);
-    zk->dB2 = dev_upload(s7.p + zk->wlo * 128, zk->wcnt * 128);
-    zk->dC = dev_upload(s8.p + zk->clo * 64, zk->ccnt * 64);
-    zk->dH = dev_upload(s9.p + zk->hlo * 64, zk->hcnt * 64);
+    zk->dA = dev_upload(ctx, s5.p + zk->wlo * 64, zk->wcnt * 64);
+    zk->dB1 = dev_upload(ctx, s6.p + zk->wlo * 64, zk->wcnt * 64);
+    zk->dB2 = dev_upload(ctx, s7.p + zk->wlo * 128, zk->wcnt * 128);
+    zk->dC = dev_upload(ctx, s8.p + zk->clo * 64, zk->ccnt * 64);
+    zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
     hipStream_t st = ctx->dev.lanes[0].stream;
-    void* d_recs = dev_upload(s4.p + 4, zk->nCoefs * 44);
+    void* d_recs = dev_upload(ctx, s4.p + 4, zk->nCoefs * 44);
     try {
       build_csr(ctx, zk.get(), d_recs);
     } catch (...) {
@@ -451,8 +456,8 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
                                                          ", witness: " + std::to_string(w.n));
   if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
   Lane& l0 = ctx->dev.lanes[0];
-  ZK_HIP(hipMemcpyAsync(zk->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, l0.stream));
-  ZK_HIP(hipStreamSynchronize(l0.stream));
+  (void)l0;
+  ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
   prove_core(ctx, zk, r_le, s_le, proof_points);
   memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
 }
@@ -569,7 +574,9 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
   int rc = PROVER_OK;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
+    auto tl0 = std::chrono::steady_clock::now();
     zk = zkey_load_impl(ctx, zkey, zkey_size);
+    const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
     uint8_t rb[32], sb[32];
     const uint8_t *rp = nullptr, *sp = nullptr;
     if (const char* e = getenv("ZKPOA_R")) {
@@ -593,8 +600,11 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
       set_err(error_msg, error_msg_maxsize, "output buffer too small");
     }
     if (getenv("ZKPOA_VERBOSE")) {
-      fprintf(stderr, "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | h-chain %.2f ms, msm phase %.2f ms, prove %.2f ms\n",
-              zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
+      fprintf(stderr,
+              "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey load %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
+              "msm phase %.2f ms, prove %.2f ms\n",
+              zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, load_ms,
+              (double)zkey_size / load_ms / 1e6, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
     }
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
@@ -671,9 +681,7 @@ extern "C" int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, 
                                                            std::to_string(zkey->nVars) + ", witness: " + std::to_string(w.n));
     if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
       throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
-    hipStream_t st = ctx->dev.lanes[0].stream;
-    ZK_HIP(hipMemcpyAsync(zkey->d_witness, w.values, (size_t)w.n * 32, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));
+    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
     prove_partials(ctx, zkey, partials);
     if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
   }

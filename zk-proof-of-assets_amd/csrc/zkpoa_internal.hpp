@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/zkpoa_prover.h"
 #include "device_ctx.hpp"
+#include "fast_upload.hpp"
 #include "host_curve.hpp"
 
 #include <string>
@@ -14,6 +15,7 @@ struct NttEngine;
 struct zkpoa_context {
   zkpoa::DeviceCtx dev;
   zkpoa::NttEngine* ntt = nullptr;
+  zkpoa::FastUploader uploader;   // pinned, multi-threaded host -> HBM path for zkey sections / witnesses
   std::string last_error;
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float lane_ms[zkpoa::DeviceCtx::kLanes][2] = {};   // per-lane {whole MSM, accumulation kernel} of the last MSM
