@@ -224,8 +224,8 @@ def main():
         for i in range(steps):
             part, k1, k0 = q.popleft().result()
             if i + inflight < steps:
-                q.append(pool.submit(msm_on, i % inflight))      # lane i % inflight is free again
-            res = combine(part)
+                q.append(pool.submit(msm_on, i % inflight))      # lane i % inflight is free again: refill it
+            res = combine(part)                                  # ... before the (blocking) collective
             k_ms += k1     # HIP events on the MSM's own stream, inside the library
             d_ms += k0
         return res, k_ms, d_ms

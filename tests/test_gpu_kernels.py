@@ -245,3 +245,21 @@ def test_ntt_roundtrip_and_linearity_large(ctx):
     s = (xs[0].astype(object) + 0)  # limb-wise sum without carries is not a field sum: use the device add
     xy = ctx.field_op(1, 1, x, y)
     assert ctx.ntt(xy, k) == ctx.field_op(1, 1, fx, fy)
+
+
+def test_msm_concurrent_lanes(ctx):
+    """Three MSMs in flight from three host threads on three lanes (what bench.py and the prover do)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    n = 1 << 16
+    a, b, d_bases = _dlog_setup(ctx, n, 31)
+    inputs = []
+    for lane in range(3):
+        limbs = _np_scalars(n, 100 + lane, "witness" if lane == 1 else "uniform")
+        inputs.append((limbs, torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).cuda()))
+    with ThreadPoolExecutor(3) as pool:
+        for _ in range(3):
+            futs = [pool.submit(ctx.msm_g1_device_lane, lane, d_bases.data_ptr(), inputs[lane][1].data_ptr(), n)
+                    for lane in range(3)]
+            for lane, f in enumerate(futs):
+                assert g16.g1_from_bytes(f.result()) == bn.g1_mul(bn.G1_GEN, _dlog_expected(inputs[lane][0], a, b))

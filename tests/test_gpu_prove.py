@@ -256,3 +256,53 @@ def test_set_shard_on_resident_key(ctx, zk):
         assert zk.prove_assemble(header, zk.sum_partials(parts), 0, 0) == want
     finally:
         circ.close()
+
+
+# ---- edge cases of the domain -------------------------------------------------------------------------------
+def _setup_small(rng, nVars, nPublic, nCons):
+    cons, w = g16.random_circuit(rng, nVars, nPublic, nCons)
+    tox = {k: rng.randrange(1, R) for k in ("tau", "alpha", "beta", "gamma", "delta")}
+    zkey, vk = g16.synthetic_setup(nVars, nPublic, cons, tox,
+                                   g1_batch=lambda s: co.fixed_base_g1(b"".join(le(k) for k in s), 8),
+                                   g2_batch=lambda s: co.fixed_base_g2(b"".join(le(k) for k in s), 8))
+    return zkey, vk, w
+
+
+@pytest.mark.parametrize("nVars,nPublic,nCons", [
+    (30, 0, 20),        # no public signals: public.json is "[]", C section has nVars-1 points
+    (40, 3, 60),        # nCons + nPublic + 1 = 64: the domain is filled exactly
+    (40, 3, 61),        # one more constraint: the domain doubles
+    (9, 1, 1),          # a single constraint
+])
+def test_prove_edge_shapes(ctx, zk, nVars, nPublic, nCons):
+    rng = random.Random(nVars * 1000 + nCons)
+    zkey, vk, w = _setup_small(rng, nVars, nPublic, nCons)
+    wt = g16.write_wtns(w)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    key = ctx.load_zkey(zkey)
+    try:
+        pts, pub = ctx.prove(key, wt, r_, s_)
+    finally:
+        key.close()
+    proof, opub = g16.prove(zkey, wt, r_, s_)
+    assert _pts_to_proof(pts) == proof and [rd(pub, i) for i in range(nPublic)] == opub
+    assert zk.public_to_json(pub, "rapidsnark") == g16.public_json_rapidsnark(opub)
+    assert zk.public_to_json(pub, "snarkjs") == g16.public_json_snarkjs(opub)
+    assert g16.verify(vk, opub, g16.proof_to_obj(proof))
+    assert zk.groth16_verify(json.dumps(vk), zk.public_to_json(pub), zk.proof_to_json(pts))
+
+
+def test_prove_degenerate_witness(ctx, zk):
+    """w = (1, 0, 0, ...): every witness MSM collapses to (at most) one base; H scalars are all zero. The
+    result must still equal the oracle's (proofs of a non-satisfying witness simply do not verify)."""
+    rng = random.Random(5)
+    zkey, vk, w = _setup_small(rng, 50, 2, 40)
+    w0 = [1] + [0] * 49
+    wt = g16.write_wtns(w0)
+    key = ctx.load_zkey(zkey)
+    try:
+        pts, pub = ctx.prove(key, wt, 0, 0)
+    finally:
+        key.close()
+    proof, _ = g16.prove(zkey, wt, 0, 0)
+    assert _pts_to_proof(pts) == proof

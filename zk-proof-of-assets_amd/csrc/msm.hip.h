@@ -514,6 +514,8 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   MsmSorted sr;
   sr.p = msm_make_plan(n, force_c);
   const MsmPlan& p = sr.p;
+  // entry positions are 32-bit: n * W (+ a few per-bucket slots) must stay below 2^32
+  if ((uint64_t)p.n * p.W + p.TB >= 0xffff0000ull) throw HipError("msm: n * windows exceeds the 32-bit entry index");
   hipStream_t st = lane.stream;
   lane_reserve(lane, msm_sort_workspace_bytes(p) + (extra ? extra(p) : 0));
   Arena& ws = lane.ws;
