@@ -27,6 +27,7 @@ namespace zkpoa {
 
 constexpr uint32_t kNttTileLog = 11;  // 2048 elements = 64 KiB of LDS per workgroup
 constexpr uint32_t kNttStridedB = 8;  // rows per tile in strided passes (x 8 columns)
+constexpr uint32_t kNttMaxStridedB = 10;  // a single strided pass may take up to 10 stages (x 2 columns)
 
 // T[i] = scale * base^(i * step) for i < count  (all Montgomery)
 static __global__ __launch_bounds__(256) void fr_pow_table_kernel(Fr base, Fr scale, uint32_t count, void* out) {
@@ -176,7 +177,12 @@ inline std::vector<NttPassDesc> ntt_plan(uint32_t k) {
   uint32_t b0 = k < kNttTileLog ? k : kNttTileLog;
   v.push_back({0, b0, 0});
   uint32_t rest = k - b0;
-  if (rest) {
+  if (rest && rest <= kNttMaxStridedB) {
+    // one strided pass of `rest` stages: tile = 2^rest rows x 2^(11 - rest) columns (>= 64-B row segments).
+    // Fewer columns coalesce less well, but a whole pass (64 B/element of traffic + one boundary twiddle,
+    // 2 modmuls/element) disappears; these sizes (n <= 2^21) also sit in the Infinity Cache.
+    v.push_back({b0, rest, kNttTileLog - rest});
+  } else if (rest) {
     uint32_t npass = (rest + kNttStridedB - 1) / kNttStridedB;
     uint32_t s = b0;
     for (uint32_t i = 0; i < npass; i++) {
