@@ -19,8 +19,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def zk():
     """The product package (zk-proof-of-assets_amd/, loaded as module zkpoa_amd)."""
-    from __graft_entry__ import load_package
-    return load_package()
+    import __graft_entry__ as entry
+    mod = entry.load_package()
+    if not (os.path.exists(mod.LIB_PATH) and os.path.exists(mod.PROVER_BIN) and os.path.exists(mod.VERIFY_BIN)):
+        entry.build()           # fresh checkout: compile the HIP library + CLIs (hipcc cross-compiles without a GPU)
+    return mod
 
 
 @pytest.fixture(scope="session")
