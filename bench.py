@@ -83,20 +83,28 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
     # owns index range rank/N of the five MSMs; partial points are all-gathered over RCCL and summed.
     circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True)
     header = circ.key.header()
-    if world > 1:
+    split = world > 1 and not args.replicated_chain and sharding.split_chain_supported(world, 1 << k)
+    if split:
+        # the H-scalar chain is split over the ranks too: rows c = rank (mod N), two all-to-alls per polynomial
+        circ.key.set_shard_split(rank, world)
+        xbufs = sharding.exchange_buffers(1 << k, world, dev)
+    elif world > 1:
         circ.key.set_shard(rank, world)
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**args.barrier_kw)
         torch.cuda.synchronize()
 
     def one_proof():
         if world == 1:
             return circ.prove(0, 0)[0]
+        if split:
+            return sharding.sharded_prove_split(ctx, circ.key, circ.d_witness.data_ptr(), header, zk.sum_partials,
+                                                zk.prove_assemble, 0, 0, dist, args.cdev, xbufs)
         return sharding.sharded_prove(lambda: ctx.prove_partials_device(circ.key, circ.d_witness.data_ptr()),
-                                      header, zk.sum_partials, zk.prove_assemble, 0, 0, dist, dev)
+                                      header, zk.sum_partials, zk.prove_assemble, 0, 0, dist, args.cdev)
 
     for _ in range(args.warmup):
         one_proof()
@@ -112,7 +120,7 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not circ.check(pts, 0, 0):
@@ -127,11 +135,13 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
             "metric": "Groth16 proofs/sec", "value": args.steps / elapsed, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic",
+            "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo "
+                                                                              "collectives; not a measurement)" if args.rehearse else ""),
             "config": {"workload": "full Groth16 prove, domain 2^%d, %d wires, %d public (%s); key and witness "
                                    "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
                        "n_coefs": ncoef, "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
-                                       "points; H-scalar chain replicated" % world) if world > 1 else "single GPU"},
+                                       "points; H-scalar chain %s" % (world, "split (four-step NTTs, 2 all-to-alls per "
+                                       "polynomial)" if split else "replicated")) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
                          "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -140,7 +150,7 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**args.barrier_kw)
         dist.destroy_process_group()
     circ.close()
     ctx.close()
@@ -153,6 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="msm_g1_2p20")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicated-chain", action="store_true",
+                    help="prove workloads, N > 1: run the whole H-scalar chain on every rank instead of splitting it")
     ap.add_argument("--inflight", type=int, default=3, help="MSMs kept in flight on separate HIP streams")
     args = ap.parse_args()
 
@@ -171,13 +183,24 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path is HIP-only (no CPU fallback)")
+    # ZKPOA_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks -- the ranks
+    # share the visible GPU(s) and the collectives run over gloo through the host. Never a measurement.
+    rehearse = os.environ.get("ZKPOA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    args.cdev = torch.device("cpu") if rehearse else dev           # where collective payloads live
+    args.barrier_kw = {} if rehearse else {"device_ids": [local_rank]}
+    args.rehearse = rehearse
     force_dist = os.environ.get("ZKPOA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with one rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload.startswith("prove_2p"):
         return bench_prove(args, zk, dist, rank, world, local_rank, dev)
@@ -215,7 +238,7 @@ def main():
     def combine(part):
         if world == 1 and not force_dist:
             return part
-        return sharding.combine_partials(zk.g1_sum, sharding.all_gather_bytes(part, dist, dev))
+        return sharding.combine_partials(zk.g1_sum, sharding.all_gather_bytes(part, dist, args.cdev))
 
     def run(steps):
         """-> (last result, sum of accumulate-kernel ms, sum of whole-MSM device ms)"""
@@ -233,7 +256,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1 or force_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**args.barrier_kw)
         torch.cuda.synchronize()
 
     run(max(args.warmup, inflight))      # also sizes every lane's workspace outside the timed region
@@ -244,7 +267,7 @@ def main():
     elapsed = time.perf_counter() - t0
     pool.shutdown()
     if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -272,7 +295,9 @@ def main():
             "metric": "G1-MSM throughput", "value": pts_total / elapsed, "unit": "pts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32x8 (254-bit modular integer)",
+            "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo collectives; not a measurement)"
+                                   if args.rehearse else ""),
             "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d points per GPU, uniform 252-bit scalars, "
                                    "bases (a+i*b)*G resident in HBM (BASELINE.json configs[1])" % logn,
                        "points_per_gpu": n_local, "sharding": "index ranges, all-gather of partial points",
@@ -308,7 +333,7 @@ def main():
                                     "seconds": tcpu}
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**args.barrier_kw)
         dist.destroy_process_group()
     ctx.close()
 

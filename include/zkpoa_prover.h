@@ -95,7 +95,7 @@ int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d
 /* ---- one proof sharded over several GPUs (BASELINE.json configs[3]) -------------------
  * The five MSMs shard by contiguous index ranges; one process per GPU owns shard `rank` of `world`:
  *   zkpoa_zkey_load_shard   uploads only that rank's byte range of zkey sections 5-9 (coefficients and
- *                           the H-scalar chain are replicated);
+ *                           the H-scalar chain are replicated; see the split chain below for sharding them);
  *   zkpoa_zkey_set_shard    restricts a fully resident key (zkpoa_zkey_load / _load_device) to a shard;
  *   zkpoa_prove_partials    -> partials = A(64) B1(64) B2(128) C(64) H(64): the shard's five MSM results;
  *   (the caller all-gathers the 384 bytes over RCCL and sums component-wise: zkpoa_g1_sum / zkpoa_g2_sum)
@@ -111,6 +111,31 @@ int zkpoa_prove_partials_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, cons
                                 uint8_t partials[384]);
 int zkpoa_prove_assemble(const uint8_t header_points[448], const uint8_t partial_sums[384],
                          const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256]);
+
+/* ---- the H-scalar chain split over the same ranks (SURVEY.md 8e rows NTT / buildABC / joinABC) -------
+ * Replaces, per rank, 1/world of snarkjs groth16_prove.js buildABC1 + 3 x (Fr.ifft, batchApplyKey, Fr.fft)
+ * + joinABC. world = G in {2, 4, 8}, G^2 <= domain n, M = n / G, Q = M / G.
+ * Rank g owns the constraint rows c = g (mod G) and ends with the H scalars of the odd-coset indices
+ * i = g (mod G); its H points are the cyclic shard H[t*G + g], so no scalar ever moves after stage 3.
+ * Each transform is a four-step NTT with ONE all-to-all (2 per polynomial for ifft -> shift -> fft):
+ *   zkpoa_witness_load       parse a .wtns and upload it into the key's witness buffer (every rank: replicated)
+ *   zkpoa_split_stage1       buildABC on the rank's rows + size-M inverse DIF of A, B, C -> d_exchange
+ *   [caller: per polynomial, all-to-all with equal splits of Q elements (RCCL all_to_all_single)]
+ *   zkpoa_split_stage2       twiddle, size-G DFT, coset scale inc^k / n, size-G DFT, twiddle: d_received -> d_exchange
+ *   [caller: the same all-to-all again]
+ *   zkpoa_split_stage3       size-M forward DIT of A, B, C + joinABC -> H scalars kept on the key handle
+ *   zkpoa_prove_partials_device(ctx, key, NULL, partials)   the five MSMs of the shard (H: cyclic shard)
+ * d_exchange / d_received: caller-owned device buffers of 3 * M * 32 bytes (A, B, C polynomial-major), e.g.
+ * the tensors handed to RCCL. Every stage returns with its stream synchronised; the caller synchronises the
+ * collective's stream before the next stage. d_witness NULL = the witness already resident on the handle. */
+int zkpoa_zkey_load_shard_split(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                                uint64_t rank, uint64_t world, zkpoa_zkey** zkey);
+int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t rank, uint64_t world);
+int zkpoa_witness_load(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer, unsigned long wtns_size,
+                       uint8_t* public_le, unsigned long public_capacity);
+int zkpoa_split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness, void* d_exchange);
+int zkpoa_split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_received, void* d_exchange);
+int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_received);
 
 /* proof_points / public -> JSON text. style 0 = rapidsnark bytes, 1 = snarkjs bytes
  * (SURVEY.md 8a row a11). Size protocol as groth16_prover. */

@@ -258,6 +258,120 @@ def test_set_shard_on_resident_key(ctx, zk):
         circ.close()
 
 
+# ---- the H-scalar chain split over the ranks too (SURVEY.md 8e rows NTT / buildABC / joinABC) --------------
+def _virtual_all_to_all(send, world):
+    """send[src][poly][M*32] -> recv[dst][poly][...]: dst receives chunk dst of every src, ordered by src --
+    what dist.all_to_all_single does per polynomial, for `world` virtual ranks living on one GPU."""
+    w, three, mb = send.shape
+    return send.view(w, three, world, mb // world).permute(2, 1, 0, 3).contiguous().view(w, three, mb)
+
+
+def _split_chain_partials(ctx, keys, world, domain, d_witness=None):
+    import torch
+    mb = domain // world * 32
+    send = torch.zeros((world, 3, mb), dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        ctx.split_stage1(keys[r], d_witness, send[r].data_ptr())
+    recv = _virtual_all_to_all(send, world)
+    for r in range(world):
+        ctx.split_stage2(keys[r], recv[r].data_ptr(), send[r].data_ptr())
+    recv = _virtual_all_to_all(send, world)
+    for r in range(world):
+        ctx.split_stage3(keys[r], recv[r].data_ptr())
+    torch.cuda.synchronize()
+    return [ctx.prove_partials_device(keys[r], None) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("tag", ["n8", "n128"])
+def test_split_chain_golden_bit_exact(ctx, zk, tag, world):
+    """Each virtual rank loads its split shard (own constraint rows, cyclic H points), the two exchanges are
+    emulated on one GPU, and the assembled proof must be the golden proof byte for byte."""
+    g = golden_case(tag)
+    rs = json.loads(g["rs.json"])
+    domain = g16.read_zkey(g["circuit.zkey"]).domainSize
+    if world * world > domain:
+        with pytest.raises(zk.ZkpoaError, match="world"):
+            ctx.load_zkey_shard_split(g["circuit.zkey"], 0, world)
+        return
+    keys = [ctx.load_zkey_shard_split(g["circuit.zkey"], r, world) for r in range(world)]
+    try:
+        with pytest.raises(zk.ZkpoaError, match="split"):
+            ctx.prove_partials(keys[0], g["witness.wtns"])           # host-witness form needs the stages
+        with pytest.raises(zk.ZkpoaError, match="stage"):
+            ctx.prove_partials_device(keys[0], None)                  # H scalars not computed yet
+        pubs = {ctx.witness_load(k, g["witness.wtns"]) for k in keys}
+        assert len(pubs) == 1
+        parts = _split_chain_partials(ctx, keys, world, domain)
+        pts = zk.prove_assemble(keys[0].header(), zk.sum_partials(parts), int(rs["r"]), int(rs["s"]))
+        assert zk.proof_to_json(pts, "rapidsnark") == g["proof_rapidsnark.json"]
+        assert zk.public_to_json(pubs.pop(), "rapidsnark") == g["public_rapidsnark.json"]
+        with pytest.raises(zk.ZkpoaError, match="stage"):
+            ctx.prove_partials_device(keys[0], None)                  # consumed: a new proof needs new stages
+    finally:
+        for k in keys:
+            k.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_split_chain_mid_size_equals_unsharded(ctx, zk, mid_circuit, world):
+    zkey, _, wt, _ = mid_circuit
+    rng = random.Random(11)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    full = ctx.load_zkey(zkey)
+    try:
+        want, pub = ctx.prove(full, wt, r_, s_)
+        header = full.header()
+    finally:
+        full.close()
+    keys = [ctx.load_zkey_shard_split(zkey, r, world) for r in range(world)]
+    try:
+        for k in keys:
+            assert ctx.witness_load(k, wt) == pub
+        parts = _split_chain_partials(ctx, keys, world, 1 << 13)
+        assert zk.prove_assemble(header, zk.sum_partials(parts), r_, s_) == want
+        # second proof on the same handles (buffers and tables reused)
+        parts2 = _split_chain_partials(ctx, keys, world, 1 << 13)
+        assert parts2 == parts
+    finally:
+        for k in keys:
+            k.close()
+
+
+@pytest.mark.parametrize("log_domain,world", [(14, 4), (18, 8), (22, 2)])
+def test_set_shard_split_on_resident_key(ctx, zk, log_domain, world):
+    """Resident synthetic key re-pointed rank by rank (what bench.py does per GPU): strided rows of the full
+    CSR + cyclic H copy. 2^18 / 2^22 also cross the multi-pass NTT plans of the size-M transforms."""
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    n_cons = (1 << log_domain) - 5000
+    circ = SyntheticCircuit(zk, ctx, log_domain, n_cons, n_public=1, seed=5, witness_like=True)
+    try:
+        want, _ = circ.prove(0, 0)
+        header = circ.key.header()
+        import torch
+        mb = (1 << log_domain) // world * 32
+        send = torch.zeros((world, 3, mb), dtype=torch.uint8, device="cuda")
+        wptr = circ.d_witness.data_ptr()
+        for r in range(world):
+            circ.key.set_shard_split(r, world)
+            ctx.split_stage1(circ.key, wptr, send[r].data_ptr())
+        recv = _virtual_all_to_all(send, world)
+        for r in range(world):
+            circ.key.set_shard_split(r, world)
+            ctx.split_stage2(circ.key, recv[r].data_ptr(), send[r].data_ptr())
+        recv = _virtual_all_to_all(send, world)
+        parts = []
+        for r in range(world):
+            circ.key.set_shard_split(r, world)
+            ctx.split_stage3(circ.key, recv[r].data_ptr())
+            parts.append(ctx.prove_partials_device(circ.key, None))
+        circ.key.set_shard(0, 1)
+        assert zk.prove_assemble(header, zk.sum_partials(parts), 0, 0) == want
+        assert circ.prove(0, 0)[0] == want          # the handle is a whole key again
+    finally:
+        circ.close()
+
+
 # ---- edge cases of the domain -------------------------------------------------------------------------------
 def _setup_small(rng, nVars, nPublic, nCons):
     cons, w = g16.random_circuit(rng, nVars, nPublic, nCons)

@@ -130,3 +130,58 @@ def test_two_rank_sharded_prove_gloo():
         assert p.exitcode == 0
     for _, got, want in results:
         assert got == want
+
+
+def _split_worker(rank, world, port, q):
+    """The product's orchestration of the split H-scalar chain (sharding.split_h_chain: stage, all-to-all,
+    stage, all-to-all, stage) over gloo, with the big-int stage model standing in for the HIP stages."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    from conftest import golden_case
+    from oracle.py import groth16 as g16
+    from split_model import SplitRank
+    load_package()
+    from zkpoa_amd import sharding
+    g = golden_case("n128")
+    zkey = g16.read_zkey(g["circuit.zkey"])
+    _, w = g16.read_wtns(g["witness.wtns"])
+    assert sharding.split_chain_supported(world, zkey.domainSize)
+    model = SplitRank(zkey, w, rank, world)
+    a = torch.zeros((3, zkey.domainSize // world * 32), dtype=torch.uint8)
+    b = torch.zeros_like(a)
+    sharding.split_h_chain(model.stage1, model.stage2, model.stage3, a, b, dist)
+    q.put((rank, model.h, g16.h_scalars(zkey, w)[rank::world]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_split_h_chain_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    for _, got, want in results:
+        assert got == want          # rank g ends with the H scalars of the odd-coset indices i = g (mod G)
+
+
+def test_split_chain_supported():
+    from __graft_entry__ import load_package
+    load_package()
+    from zkpoa_amd import sharding
+    assert sharding.split_chain_supported(8, 1 << 26) and sharding.split_chain_supported(2, 4)
+    assert not sharding.split_chain_supported(3, 1 << 20)      # replicated chain instead
+    assert not sharding.split_chain_supported(8, 32)
+    assert not sharding.split_chain_supported(1, 1 << 20)

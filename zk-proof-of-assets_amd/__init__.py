@@ -30,6 +30,8 @@ EXPORTS = [
     "zkpoa_zkey_load_device", "zkpoa_prove_device",
     "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
+    "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
+    "zkpoa_split_stage1", "zkpoa_split_stage2", "zkpoa_split_stage3",
     "zkpoa_proof_to_json", "zkpoa_public_to_json",
     "zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_ntt", "zkpoa_h_scalars",
     "zkpoa_msm_g1_device", "zkpoa_msm_g2_device", "zkpoa_ntt_device",
@@ -108,6 +110,13 @@ def lib():
         L.zkpoa_zkey_load_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_uint64,
                                             ctypes.c_uint64, c_void_pp]
         L.zkpoa_zkey_set_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.zkpoa_zkey_load_shard_split.argtypes = L.zkpoa_zkey_load_shard.argtypes
+        L.zkpoa_zkey_set_shard_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.zkpoa_witness_load.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
+                                         ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_split_stage1.argtypes = [ctypes.c_void_p] * 4
+        L.zkpoa_split_stage2.argtypes = [ctypes.c_void_p] * 4
+        L.zkpoa_split_stage3.argtypes = [ctypes.c_void_p] * 3
         L.zkpoa_zkey_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.zkpoa_prove_partials.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
@@ -280,6 +289,34 @@ class Context:
                     "zkpoa_zkey_load_shard")
         return key
 
+    def load_zkey_shard_split(self, zkey_bytes, rank, world):
+        """Like load_zkey_shard, with the H-scalar chain split too: this rank's constraint rows (c = rank mod
+        world) of the coefficient list and the cyclic H-point shard H[t*world + rank]."""
+        key = ZKey.__new__(ZKey)
+        key._ctx = self
+        key._h = ctypes.c_void_p()
+        p, k = _buf(zkey_bytes)
+        self._check(lib().zkpoa_zkey_load_shard_split(self._h, p, len(zkey_bytes), rank, world, ctypes.byref(key._h)),
+                    "zkpoa_zkey_load_shard_split")
+        return key
+
+    def witness_load(self, zkey, wtns_bytes):
+        """Parse a .wtns and upload it into the key's witness buffer -> public bytes."""
+        pw, kw = _buf(wtns_bytes)
+        npub = zkey.info()[1]
+        pub = ctypes.create_string_buffer(max(1, 32 * npub))
+        self._check(lib().zkpoa_witness_load(self._h, zkey._h, pw, len(wtns_bytes), pub, 32 * npub), "zkpoa_witness_load")
+        return pub.raw[:32 * npub]
+
+    def split_stage1(self, zkey, d_witness, d_exchange):
+        self._check(lib().zkpoa_split_stage1(self._h, zkey._h, d_witness, d_exchange), "zkpoa_split_stage1")
+
+    def split_stage2(self, zkey, d_received, d_exchange):
+        self._check(lib().zkpoa_split_stage2(self._h, zkey._h, d_received, d_exchange), "zkpoa_split_stage2")
+
+    def split_stage3(self, zkey, d_received):
+        self._check(lib().zkpoa_split_stage3(self._h, zkey._h, d_received), "zkpoa_split_stage3")
+
     def prove_partials(self, zkey, wtns_bytes):
         """-> (partials[384] = A|B1|B2|C|H MSM results of the key's shard, public bytes)"""
         pw, kw = _buf(wtns_bytes)
@@ -337,6 +374,11 @@ class ZKey:
         """Restrict a fully resident key to shard `rank` of `world` (for zkpoa_prove_partials)."""
         if lib().zkpoa_zkey_set_shard(self._h, rank, world) != PROVER_OK:
             raise ZkpoaError("zkpoa_zkey_set_shard failed")
+
+    def set_shard_split(self, rank, world):
+        """set_shard + the H-scalar chain split over the same ranks (world in 2, 4, 8)."""
+        self._ctx._check(lib().zkpoa_zkey_set_shard_split(self._ctx._h, self._h, rank, world),
+                         "zkpoa_zkey_set_shard_split")
 
     def header(self):
         """alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128), wire format."""

@@ -24,32 +24,41 @@ struct CoefRec {  // 44 bytes, 4-byte aligned, as stored in zkey section 4 after
 };
 static_assert(sizeof(CoefRec) == 44, "coef record");
 
+constexpr uint32_t kAbcSkip = 0xffffffffu;   // rank of a record that belongs to another rank's constraint rows
+
 // pass 1: validate + histogram rows, remember the rank inside the row. err[0] != 0 on bad records.
+// Split chain (buildABC row): a rank keeps the constraints c = part (mod 2^log_parts) only and
+// numbers them c >> log_parts; log_parts = 0 keeps everything.
 static __global__ __launch_bounds__(256) void abc_count_kernel(const CoefRec* __restrict__ recs, uint64_t ncoef,
-                                                               uint32_t domain, uint32_t nvars,
-                                                               uint32_t* __restrict__ row_cnt,
+                                                               uint32_t domain, uint32_t nvars, uint32_t log_parts,
+                                                               uint32_t part, uint32_t* __restrict__ row_cnt,
                                                                uint32_t* __restrict__ rank, uint32_t* __restrict__ err) {
   uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= ncoef) return;
   uint32_t m = recs[i].m, c = recs[i].c, s = recs[i].s;
   if (m > 1u || c >= domain || s >= nvars) {
     atomicOr(err, 1u);
-    rank[i] = 0;
+    rank[i] = kAbcSkip;
     return;
   }
-  rank[i] = atomicAdd(&row_cnt[2u * c + m], 1u);
+  if ((c & ((1u << log_parts) - 1u)) != part) {
+    rank[i] = kAbcSkip;
+    return;
+  }
+  rank[i] = atomicAdd(&row_cnt[2u * (c >> log_parts) + m], 1u);
 }
 
 // pass 2: scatter into CSR order
 static __global__ __launch_bounds__(256) void abc_scatter_kernel(const CoefRec* __restrict__ recs, uint64_t ncoef,
+                                                                 uint32_t log_parts,
                                                                  const uint32_t* __restrict__ row_ptr,
                                                                  const uint32_t* __restrict__ rank,
                                                                  uint32_t* __restrict__ sig, void* __restrict__ vals) {
   uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= ncoef) return;
   uint32_t m = recs[i].m, c = recs[i].c;
-  if (m > 1u) return;
-  uint32_t pos = row_ptr[2u * c + m] + rank[i];
+  if (rank[i] == kAbcSkip) return;
+  uint32_t pos = row_ptr[2u * (c >> log_parts) + m] + rank[i];
   sig[pos] = recs[i].s;
   Fr v;
 #pragma unroll
@@ -69,31 +78,44 @@ ZK_DEV Fr abc_row_sum(const uint32_t* __restrict__ row_ptr, uint32_t row, const 
   return acc;
 }
 
-// one thread per constraint c: A_T[c], B_T[c], C_T[c] = A (x) B
+// one thread per output t < count: CSR row pair of constraint c = row_off + row_stride * t ->
+// A_T[t], B_T[t], C_T[t] = A (x) B. (row_off, row_stride) = (0, 1) walks the whole CSR; a rank of the
+// split chain walks its cyclic rows of a full CSR with (rank, world).
 static __global__ __launch_bounds__(256) void abc_rows_kernel(const uint32_t* __restrict__ row_ptr,
                                                               const uint32_t* __restrict__ sig,
                                                               const void* __restrict__ vals,
-                                                              const void* __restrict__ witness, uint32_t domain,
+                                                              const void* __restrict__ witness, uint32_t count,
+                                                              uint32_t row_off, uint32_t row_stride,
                                                               void* __restrict__ A, void* __restrict__ B,
                                                               void* __restrict__ C) {
-  uint32_t c = blockIdx.x * 256u + threadIdx.x;
-  if (c >= domain) return;
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= count) return;
+  uint32_t c = row_off + row_stride * t;
   Fr a = abc_row_sum(row_ptr, 2u * c, sig, vals, witness);
   Fr b = abc_row_sum(row_ptr, 2u * c + 1u, sig, vals, witness);
-  store_field(reinterpret_cast<char*>(A) + 32 * (size_t)c, a);
-  store_field(reinterpret_cast<char*>(B) + 32 * (size_t)c, b);
-  store_field(reinterpret_cast<char*>(C) + 32 * (size_t)c, a * b);
+  store_field(reinterpret_cast<char*>(A) + 32 * (size_t)t, a);
+  store_field(reinterpret_cast<char*>(B) + 32 * (size_t)t, b);
+  store_field(reinterpret_cast<char*>(C) + 32 * (size_t)t, a * b);
 }
 
-// P[i] = fromMontgomery(A[i] (x) B[i] - C[i]); written over A
-static __global__ __launch_bounds__(256) void abc_join_kernel(void* __restrict__ A, const void* __restrict__ B,
-                                                              const void* __restrict__ C, uint32_t domain) {
+// P[i] = fromMontgomery(A[i] (x) B[i] - C[i]); out may be A
+static __global__ __launch_bounds__(256) void abc_join_kernel(const void* A, const void* __restrict__ B,
+                                                              const void* __restrict__ C, uint32_t domain, void* out) {
   uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= domain) return;
   Fr a = load_field<Fr>(reinterpret_cast<const char*>(A) + 32 * (size_t)i);
   Fr b = load_field<Fr>(reinterpret_cast<const char*>(B) + 32 * (size_t)i);
   Fr c = load_field<Fr>(reinterpret_cast<const char*>(C) + 32 * (size_t)i);
-  store_field(reinterpret_cast<char*>(A) + 32 * (size_t)i, (a * b - c).from_mont());
+  store_field(reinterpret_cast<char*>(out) + 32 * (size_t)i, (a * b - c).from_mont());
+}
+
+// dst[i] = src[off + stride * i], 64-byte elements (G1 affine points): the cyclic H-point shard of a split chain
+static __global__ __launch_bounds__(256) void strided_copy64_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                                    uint64_t count, uint32_t off, uint32_t stride) {
+  uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // one 16-byte quarter per thread
+  if (q >= count * 4u) return;
+  uint64_t i = q >> 2;
+  dst[q] = src[((uint64_t)off + (uint64_t)stride * i) * 4u + (q & 3u)];
 }
 
 }  // namespace zkpoa

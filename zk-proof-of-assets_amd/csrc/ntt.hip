@@ -24,6 +24,15 @@ void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k) {
   HFr ninv = HFr::from_u64(1ull << k).inv();
   (void)e->pow_tables(st, k, inc, ninv, k);
 }
+void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
+  engine(ctx)->dif(st, d_data, k, inverse);
+}
+void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
+  engine(ctx)->dit(st, d_data, k, inverse);
+}
+void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h) {
+  engine(ctx)->split_mid(st, in, out, k, G, h);
+}
 void ntt_release(zkpoa_context* ctx) {
   if (ctx->ntt) {
     ctx->ntt->release();

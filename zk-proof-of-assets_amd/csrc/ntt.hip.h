@@ -165,6 +165,67 @@ static __global__ __launch_bounds__(256) void fr_scale_const_kernel(void* data, 
   store_field(d, load_field<Fr>(d) * c);
 }
 
+// ---- H-scalar chain split over G ranks (NTT row) -----------------------------------------
+// n = G * M. Rank g holds X[g + G t] (cyclic rows), runs a size-M DIF with root w^-G (slot p = bitrev(k1)),
+// and the ranks exchange so that rank h owns slots [h*Q, (h+1)*Q), Q = M / G, of every rank's transform.
+// This kernel is everything between the two exchanges, per slot p (k1 = bitrev_M(p)):
+//   v[g]  = in[g][p] * w^-(g k1)                       four-step twiddle of the inverse transform
+//   a[k2] = sum_g v[g] * (w^-M)^(g k2)                 size-G DFT: coefficient k = k1 + M k2 (unscaled)
+//   a[k2] *= inc^k / n                                  batchApplyKey(1, inc) and the 1/n of the ifft
+//   b[i2] = sum_k2 a[k2] * (w^M)^(k2 i2)               size-G DFT of the forward transform
+//   out[i2][p] = b[i2] * w^(k1 i2)                      its four-step twiddle
+// after the second exchange rank i2 holds slot-ordered input of a size-M DIT whose output t is the
+// evaluation at odd-coset index t*G + i2. G <= 8, so the two size-G DFTs are direct sums.
+struct SplitRoots {
+  Fr inv[8];   // (w^-M)^e, e < G
+  Fr fwd[8];   // (w^M)^e
+};
+
+template <uint32_t G>
+static __global__ __launch_bounds__(256) void ntt_split_mid_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                   uint32_t Q, uint32_t slot0, uint32_t logM,
+                                                                   SplitRoots roots, const void* __restrict__ inv_hi,
+                                                                   const void* __restrict__ inv_lo,
+                                                                   const void* __restrict__ fwd_hi,
+                                                                   const void* __restrict__ fwd_lo, uint32_t L,
+                                                                   const void* __restrict__ cos_hi,
+                                                                   const void* __restrict__ cos_lo, uint32_t Lc) {
+  uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+  if (pl >= Q) return;
+  const uint32_t p = slot0 + pl;
+  const uint32_t k1 = logM ? (__brev(p) >> (32u - logM)) : 0u;
+  const char* src = reinterpret_cast<const char*>(in);
+  char* dst = reinterpret_cast<char*>(out);
+  Fr v[G], a[G];
+#pragma unroll
+  for (uint32_t g = 0; g < G; g++) v[g] = load_field<Fr>(src + 32 * ((size_t)g * Q + pl));
+  {
+    Fr t = tw_lookup(inv_hi, inv_lo, L, k1), pw = t;
+#pragma unroll
+    for (uint32_t g = 1; g < G; g++) {
+      v[g] = v[g] * pw;
+      if (g + 1 < G) pw = pw * t;
+    }
+  }
+#pragma unroll
+  for (uint32_t k2 = 0; k2 < G; k2++) {
+    Fr acc = v[0];
+#pragma unroll
+    for (uint32_t g = 1; g < G; g++) acc = acc + v[g] * roots.inv[(g * k2) & (G - 1u)];
+    a[k2] = acc * tw_lookup(cos_hi, cos_lo, Lc, k1 + (k2 << logM));
+  }
+  Fr t = tw_lookup(fwd_hi, fwd_lo, L, k1), pw = Fr::one();
+#pragma unroll
+  for (uint32_t i2 = 0; i2 < G; i2++) {
+    Fr acc = a[0];
+#pragma unroll
+    for (uint32_t k2 = 1; k2 < G; k2++) acc = acc + a[k2] * roots.fwd[(k2 * i2) & (G - 1u)];
+    if (i2) acc = acc * pw;
+    store_field(dst + 32 * ((size_t)i2 * Q + pl), acc);
+    pw = pw * t;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct NttPassDesc {
   uint32_t s_lo, B, logT;
@@ -316,6 +377,36 @@ struct NttEngine {
     hipLaunchKernelGGL((fr_scale_pow_kernel<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, k,
                        (const void*)tb.first, (const void*)tb.second, (k + 1) / 2);
     dit(st, d, k, false);
+  }
+
+  // the part of to_odd_coset between the two exchanges when the transform is split over G ranks
+  // (ntt_split_mid_kernel); k = log2 n of the whole domain, h = this rank, in/out: [G][M / G] elements.
+  void split_mid(hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h) {
+    uint32_t lg = 0;
+    while ((1u << lg) < G) lg++;
+    const uint32_t logM = k - lg, Q = (1u << logM) / G;
+    const NttTables& ti = tables(st, k, true);
+    const NttTables& tf = tables(st, k, false);
+    HFr inc = (k == 28) ? HFr::from_u64(25) : hfr_root_of_unity(k + 1);
+    auto tc = pow_tables(st, k, inc, HFr::from_u64(1ull << k).inv(), k);
+    SplitRoots roots;
+    HFr wf = hpow2(hfr_root_of_unity(k), logM), wi = wf.inv(), af = HFr::one(), ai = HFr::one();
+    for (uint32_t e = 0; e < 8; e++) {
+      roots.fwd[e] = to_dev(af);
+      roots.inv[e] = to_dev(ai);
+      af = af * wf;
+      ai = ai * wi;
+    }
+    dim3 grid((Q + 255) / 256), block(256);
+    const uint32_t Lc = (k + 1) / 2;
+#define ZK_SPLIT_MID(GG)                                                                                            \
+  hipLaunchKernelGGL((ntt_split_mid_kernel<GG>), grid, block, 0, st, in, out, Q, h * Q, logM, roots,                \
+                     (const void*)ti.hi, (const void*)ti.lo, (const void*)tf.hi, (const void*)tf.lo, ti.L,          \
+                     (const void*)tc.first, (const void*)tc.second, Lc)
+    if (G == 2) ZK_SPLIT_MID(2);
+    else if (G == 4) ZK_SPLIT_MID(4);
+    else ZK_SPLIT_MID(8);
+#undef ZK_SPLIT_MID
   }
 
   void release() {

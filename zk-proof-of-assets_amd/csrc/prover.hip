@@ -114,6 +114,14 @@ struct zkpoa_zkey {
   uint64_t wlo = 0, wcnt = 0, wbase = 0;   // A, B1, B2: wire indices [wlo, wlo + wcnt)
   uint64_t clo = 0, ccnt = 0, cbase = 0;   // C: section indices (wire nPublic+1+idx)
   uint64_t hlo = 0, hcnt = 0, hbase = 0;   // H: domain indices
+  // Split H-scalar chain (SURVEY.md 8e rows NTT / buildABC / joinABC): split_world = G > 1 ranks each own the
+  // constraint rows c = split_rank (mod G) and end up with the H scalars of the odd-coset indices
+  // i = split_rank (mod G), so the H points are sharded cyclically: dHs[t] = H[t*G + split_rank].
+  uint32_t split_world = 0, split_rank = 0, split_log = 0;
+  bool csr_local = false;        // CSR holds only this rank's rows, renumbered c >> split_log
+  void* dHs = nullptr;           // cyclic H shard (owned), domain / split_world points
+  mutable bool h_ready = false;  // d_abc[0 .. domain/split_world) holds this proof's H scalars (stage 3 done)
+  uint64_t nCoefsLocal = 0;
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
   }
@@ -132,10 +140,10 @@ struct zkpoa_zkey {
     if (owns_points)
       for (void* p : pts)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness};
+    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
-    dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = nullptr;
+    dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = nullptr;
     d_row_ptr = d_sig = nullptr;
   }
 };
@@ -143,40 +151,67 @@ struct zkpoa_zkey {
 namespace {
 
 // CSR of the coefficient list by output row (2*c + m); d_recs = device copy of the 44-byte records.
-// Also allocates the A/B/C work area and the witness buffer, and builds the NTT tables.
-void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs) {
+// Also allocates the A/B/C work area and the witness buffer. With split_log > 0 (split chain loaded from a
+// file) only the records of this rank's constraints are kept, rows renumbered c >> split_log.
+void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool local_rows = false) {
   hipStream_t st = ctx->dev.lanes[0].stream;
-  const uint32_t rows = 2 * zk->domain;
+  const uint32_t lp = local_rows ? zk->split_log : 0u, part = local_rows ? zk->split_rank : 0u;
+  const uint32_t rows = 2 * (zk->domain >> lp);
   const uint64_t n = zk->domain, m = zk->nVars;
-  if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * n * 32));
+  // work area: the unsplit chain transforms A_T, B_T, C_T in place; a file-loaded split shard only keeps its
+  // n / G H scalars here (the transforms run in the caller's exchange buffers)
+  if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, local_rows ? (size_t)(n >> lp) * 32 : (size_t)3 * n * 32));
   if (!zk->d_witness) ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
   DevBuf d_cnt((size_t)rows * 4), d_rank((size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4),
       d_bs(((size_t)rows / kScanTile + 2) * 4), d_misc(64);
   ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
-  ZK_HIP(hipMalloc(&zk->d_sig, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4));
-  ZK_HIP(hipMalloc(&zk->d_vals, (size_t)(zk->nCoefs ? zk->nCoefs : 1) * 32));
   ZK_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)rows * 4, st));
   ZK_HIP(hipMemsetAsync(d_misc.p, 0, 64, st));
   uint32_t* misc = (uint32_t*)d_misc.p;
+  uint32_t grid = (uint32_t)((zk->nCoefs + 255) / 256);
+  uint32_t herr = 0, total = 0;
   if (zk->nCoefs) {
-    uint32_t grid = (uint32_t)((zk->nCoefs + 255) / 256);
     hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs, zk->domain,
-                       zk->nVars, (uint32_t*)d_cnt.p, (uint32_t*)d_rank.p, misc + 4);
+                       zk->nVars, lp, part, (uint32_t*)d_cnt.p, (uint32_t*)d_rank.p, misc + 4);
     scan_u32(st, (const uint32_t*)d_cnt.p, rows, 0, 0, zk->d_row_ptr, (uint32_t*)d_bs.p, misc, nullptr);
-    hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs,
-                       (const uint32_t*)zk->d_row_ptr, (const uint32_t*)d_rank.p, zk->d_sig, zk->d_vals);
+    ZK_HIP(hipMemcpyAsync(&total, zk->d_row_ptr + rows, 4, hipMemcpyDeviceToHost, st));
   } else {
     ZK_HIP(hipMemsetAsync(zk->d_row_ptr, 0, ((size_t)rows + 1) * 4, st));
   }
-  uint32_t herr = 0;
   ZK_HIP(hipMemcpyAsync(&herr, misc + 4, 4, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
   if (herr) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
+  zk->nCoefsLocal = total;
+  zk->csr_local = local_rows;
+  ZK_HIP(hipMalloc(&zk->d_sig, (size_t)(total ? total : 1) * 4));
+  ZK_HIP(hipMalloc(&zk->d_vals, (size_t)(total ? total : 1) * 32));
+  if (zk->nCoefs) {
+    hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)d_recs, zk->nCoefs, lp,
+                       (const uint32_t*)zk->d_row_ptr, (const uint32_t*)d_rank.p, zk->d_sig, zk->d_vals);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+  }
+}
+
+// split chain: world must be a power of two <= 8 with world^2 <= domain (every rank owns whole slots of
+// every other rank's transform)
+void check_split(const zkpoa_zkey* zk, uint64_t rank, uint64_t world) {
+  if (world < 2 || world > 8 || (world & (world - 1)) || rank >= world)
+    throw ProverError(PROVER_ERROR, "split chain: world must be 2, 4 or 8 and rank < world");
+  if ((uint64_t)zk->domain < world * world)
+    throw ProverError(PROVER_ERROR, "split chain: domain smaller than world^2");
+}
+
+void set_split(zkpoa_zkey* zk, uint64_t rank, uint64_t world) {
+  zk->split_world = (uint32_t)world;
+  zk->split_rank = (uint32_t)rank;
+  zk->split_log = world == 2 ? 1 : (world == 4 ? 2 : 3);
+  zk->h_ready = false;
 }
 
 zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
-                           uint64_t world = 1) {
+                           uint64_t world = 1, bool split = false) {
   Sections secs = parse_binfile(buf, size, "zkey", 2);
   const Section& s1 = need(secs, 1, "1 (protocol)");
   if (s1.len < 4 || rd_u32(s1.p) != 1) throw ProverError(PROVER_ERROR, "zkey file is not groth16");
@@ -224,23 +259,45 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
   zk->wbase = zk->wlo;
   zk->cbase = zk->clo;
   zk->hbase = zk->hlo;
+  if (split) {
+    check_split(zk.get(), rank, world);
+    set_split(zk.get(), rank, world);
+  }
   try {
     // each rank uploads only its byte range of every point section
     zk->dA = dev_upload(ctx, s5.p + zk->wlo * 64, zk->wcnt * 64);
     zk->dB1 = dev_upload(ctx, s6.p + zk->wlo * 64, zk->wcnt * 64);
     zk->dB2 = dev_upload(ctx, s7.p + zk->wlo * 128, zk->wcnt * 128);
     zk->dC = dev_upload(ctx, s8.p + zk->clo * 64, zk->ccnt * 64);
-    zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
+    if (split) {
+      // cyclic H shard: H[t * world + rank], gathered on the host (the section is walked once per rank)
+      const uint64_t cnt = n / world;
+      std::vector<uint8_t> stage(cnt * 64);
+      const unsigned nthreads = 6;
+      std::vector<std::thread> th;
+      for (unsigned k = 0; k < nthreads; k++)
+        th.emplace_back([&, k] {
+          for (uint64_t t = cnt * k / nthreads; t < cnt * (k + 1) / nthreads; t++)
+            memcpy(stage.data() + t * 64, s9.p + (t * world + rank) * 64, 64);
+        });
+      for (auto& t : th) t.join();
+      zk->dHs = dev_upload(ctx, stage.data(), cnt * 64);
+      zk->hlo = zk->hbase = 0;
+      zk->hcnt = 0;   // no contiguous H range on this handle
+    } else {
+      zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
+    }
     hipStream_t st = ctx->dev.lanes[0].stream;
     void* d_recs = dev_upload(ctx, s4.p + 4, zk->nCoefs * 44);
     try {
-      build_csr(ctx, zk.get(), d_recs);
+      build_csr(ctx, zk.get(), d_recs, split);
     } catch (...) {
       (void)hipFree(d_recs);
       throw;
     }
     (void)hipFree(d_recs);
     ntt_prepare(ctx, st, zk->power);
+    if (split) ntt_prepare(ctx, st, zk->power - zk->split_log);
     ZK_HIP(hipStreamSynchronize(st));
   } catch (...) {
     zk->release();
@@ -256,12 +313,58 @@ void h_chain(zkpoa_context* ctx, hipStream_t st, const uint32_t* row_ptr, const 
   char* B = A + (size_t)domain * 32;
   char* C = B + (size_t)domain * 32;
   uint32_t grid = (domain + 255) / 256;
-  hipLaunchKernelGGL(abc_rows_kernel, dim3(grid), dim3(256), 0, st, row_ptr, sig, vals, d_witness, domain, (void*)A,
-                     (void*)B, (void*)C);
+  hipLaunchKernelGGL(abc_rows_kernel, dim3(grid), dim3(256), 0, st, row_ptr, sig, vals, d_witness, domain, 0u, 1u,
+                     (void*)A, (void*)B, (void*)C);
   ntt_to_odd_coset(ctx, st, A, power);
   ntt_to_odd_coset(ctx, st, B, power);
   ntt_to_odd_coset(ctx, st, C, power);
-  hipLaunchKernelGGL(abc_join_kernel, dim3(grid), dim3(256), 0, st, (void*)A, (const void*)B, (const void*)C, domain);
+  hipLaunchKernelGGL(abc_join_kernel, dim3(grid), dim3(256), 0, st, (const void*)A, (const void*)B, (const void*)C,
+                     domain, (void*)A);
+}
+
+// ---- split chain: three local stages around two all-to-all exchanges the caller runs ----
+// Exchange buffers (caller's device memory, e.g. torch tensors handed to RCCL): 3 polynomials (A, B, C) x
+// M = domain / G elements x 32 B, polynomial-major. Between stage 1 and 2, and between 2 and 3, every
+// polynomial is exchanged with equal splits of Q = M / G elements (all_to_all_single semantics).
+void split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log;
+  char* A = reinterpret_cast<char*>(d_x);
+  char* B = A + (size_t)M * 32;
+  char* C = B + (size_t)M * 32;
+  zk->h_ready = false;
+  // buildABC for the constraint rows c = rank (mod G): a rank-local CSR is already renumbered
+  hipLaunchKernelGGL(abc_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const uint32_t*)zk->d_row_ptr,
+                     (const uint32_t*)zk->d_sig, (const void*)zk->d_vals, (const void*)zk->d_witness, M,
+                     zk->csr_local ? 0u : zk->split_rank, zk->csr_local ? 1u : zk->split_world, (void*)A, (void*)B,
+                     (void*)C);
+  for (char* X : {A, B, C}) ntt_dif(ctx, st, X, kM, true);
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+}
+
+void split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zk, const void* d_in, void* d_out) {
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  const size_t M = zk->domain >> zk->split_log;
+  for (int x = 0; x < 3; x++)
+    ntt_split_mid(ctx, st, reinterpret_cast<const char*>(d_in) + x * M * 32, reinterpret_cast<char*>(d_out) + x * M * 32,
+                  zk->power, zk->split_world, zk->split_rank);
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+}
+
+void split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log;
+  char* A = reinterpret_cast<char*>(d_x);
+  char* B = A + (size_t)M * 32;
+  char* C = B + (size_t)M * 32;
+  for (char* X : {A, B, C}) ntt_dit(ctx, st, X, kM, false);
+  hipLaunchKernelGGL(abc_join_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const void*)A, (const void*)B,
+                     (const void*)C, M, zk->d_abc);
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+  zk->h_ready = true;
 }
 
 HFr hfr_from_le(const uint8_t* le) { return HFr::from_bytes(le); }
@@ -322,7 +425,11 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   const char* pB1 = reinterpret_cast<const char*>(zk->dB1) + (zk->wlo - zk->wbase) * 64;
   const char* pB2 = reinterpret_cast<const char*>(zk->dB2) + (zk->wlo - zk->wbase) * 128;
   const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
-  const char* pH = reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
+  const bool split = zk->split_world > 1;
+  if (split && !zk->h_ready)
+    throw ProverError(PROVER_ERROR, "split chain: run zkpoa_split_stage1/2/3 for this witness before zkpoa_prove_partials");
+  const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
+                         : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
   const char* witW = wit + zk->wlo * 32;
   const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
   auto guarded = [&](int slot, std::function<void()> fn) {
@@ -358,9 +465,16 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   std::exception_ptr main_err;
   try {
     ZK_HIP(hipEventRecord(ctx->ev_a[5], l0.stream));
-    h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_witness, zk->domain, zk->power, zk->d_abc);
+    if (!split)
+      h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_witness, zk->domain, zk->power, zk->d_abc);
     ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
-    msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0]);
+    if (split) {
+      // the three stages left this rank's H scalars (odd-coset indices = rank mod G) in d_abc[0 .. n/G)
+      msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0]);
+      zk->h_ready = false;
+    } else {
+      msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0]);
+    }
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
   } catch (...) {
     main_err = std::current_exception();
@@ -430,7 +544,7 @@ void zkey_header_bytes(const zkpoa_zkey* zk, uint8_t out[448]) {
 }
 
 bool is_full_key(const zkpoa_zkey* zk) {
-  return zk->wlo == 0 && zk->wcnt == zk->nVars && zk->clo == 0 && zk->ccnt == (uint64_t)zk->nVars - zk->nPublic - 1 &&
+  return zk->split_world <= 1 && zk->wlo == 0 && zk->wcnt == zk->nVars && zk->clo == 0 && zk->ccnt == (uint64_t)zk->nVars - zk->nPublic - 1 &&
          zk->hlo == 0 && zk->hcnt == zk->domain;
 }
 
@@ -658,8 +772,104 @@ extern "C" int zkpoa_zkey_load_shard(zkpoa_context* ctx, const void* zkey_buffer
 
 extern "C" int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t world) {
   if (!zkey || world == 0 || rank >= world) return PROVER_ERROR;
-  if (zkey->wbase || zkey->cbase || zkey->hbase) return PROVER_ERROR;  // only a fully resident key can be re-sharded
+  if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH)
+    return PROVER_ERROR;  // only a fully resident key can be re-sharded
   zkey->set_shard(rank, world);
+  zkey->split_world = zkey->split_rank = zkey->split_log = 0;
+  zkey->h_ready = false;
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_load_shard_split(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                                           uint64_t rank, uint64_t world, zkpoa_zkey** out) {
+  if (!ctx || !out || !zkey_buffer) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size, rank, world, true);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t rank, uint64_t world) {
+  if (!ctx || !zkey) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH)
+      throw ProverError(PROVER_ERROR, "only a fully resident key can be re-sharded");
+    check_split(zkey, rank, world);
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    const uint64_t cnt = zkey->domain / world;
+    if (zkey->dHs) {
+      ZK_HIP(hipFree(zkey->dHs));
+      zkey->dHs = nullptr;
+    }
+    ZK_HIP(hipMalloc(&zkey->dHs, cnt * 64));
+    hipLaunchKernelGGL(strided_copy64_kernel, dim3((uint32_t)((cnt * 4 + 255) / 256)), dim3(256), 0, st,
+                       (const uint4*)zkey->dH, (uint4*)zkey->dHs, cnt, (uint32_t)rank, (uint32_t)world);
+    zkey->set_shard(rank, world);
+    set_split(zkey, rank, world);
+    ntt_prepare(ctx, st, zkey->power - zkey->split_log);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_witness_load(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer,
+                                  unsigned long wtns_size, uint8_t* public_le, unsigned long public_capacity) {
+  if (!ctx || !zkey || !wtns_buffer) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    WtnsView w = parse_wtns(reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size);
+    if (w.n != zkey->nVars)
+      throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " +
+                                                           std::to_string(zkey->nVars) + ", witness: " + std::to_string(w.n));
+    if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
+      throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
+    zkey->h_ready = false;
+    if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness, void* d_exchange) {
+  if (!ctx || !zkey || !d_exchange) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (zkey->split_world < 2) throw ProverError(PROVER_ERROR, "split chain: the key handle is not a split shard");
+    hipStream_t st = ctx->dev.lanes[0].stream;
+    if (d_witness && d_witness != zkey->d_witness)
+      ZK_HIP(hipMemcpyAsync(zkey->d_witness, d_witness, (size_t)zkey->nVars * 32, hipMemcpyDeviceToDevice, st));
+    split_stage1(ctx, zkey, d_exchange);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_received, void* d_exchange) {
+  if (!ctx || !zkey || !d_received || !d_exchange || d_received == d_exchange) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (zkey->split_world < 2) throw ProverError(PROVER_ERROR, "split chain: the key handle is not a split shard");
+    split_stage2(ctx, zkey, d_received, d_exchange);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_received) {
+  if (!ctx || !zkey || !d_received) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (zkey->split_world < 2) throw ProverError(PROVER_ERROR, "split chain: the key handle is not a split shard");
+    split_stage3(ctx, zkey, d_received);
+  }
+  ZK_PROVER_CATCH(ctx)
   return PROVER_OK;
 }
 
@@ -681,6 +891,9 @@ extern "C" int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, 
                                                            std::to_string(zkey->nVars) + ", witness: " + std::to_string(w.n));
     if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
       throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
+    if (zkey->split_world > 1)
+      throw ProverError(PROVER_ERROR, "split chain: use zkpoa_witness_load, zkpoa_split_stage1/2/3, then "
+                                      "zkpoa_prove_partials_device with a NULL witness");
     ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
     prove_partials(ctx, zkey, partials);
     if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
@@ -691,11 +904,11 @@ extern "C" int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, 
 
 extern "C" int zkpoa_prove_partials_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
                                            uint8_t partials[384]) {
-  if (!ctx || !zkey || !d_witness || !partials) return PROVER_ERROR;
+  if (!ctx || !zkey || !partials) return PROVER_ERROR;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
     hipStream_t st = ctx->dev.lanes[0].stream;
-    if (d_witness != zkey->d_witness) {
+    if (d_witness && d_witness != zkey->d_witness) {
       ZK_HIP(hipMemcpyAsync(zkey->d_witness, d_witness, (size_t)zkey->nVars * 32, hipMemcpyDeviceToDevice, st));
       ZK_HIP(hipStreamSynchronize(st));
     }
@@ -848,10 +1061,10 @@ extern "C" int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned 
     if (ncoef) {
       uint32_t grid = (uint32_t)((ncoef + 255) / 256);
       hipLaunchKernelGGL(abc_count_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)recs.p, ncoef, domain,
-                         (uint32_t)n_vars, (uint32_t*)cnt.p, (uint32_t*)rank.p, (uint32_t*)misc.p + 4);
+                         (uint32_t)n_vars, 0u, 0u, (uint32_t*)cnt.p, (uint32_t*)rank.p, (uint32_t*)misc.p + 4);
       scan_u32(st, (const uint32_t*)cnt.p, rows, 0, 0, (uint32_t*)row_ptr.p, (uint32_t*)bs.p, (uint32_t*)misc.p,
                nullptr);
-      hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)recs.p, ncoef,
+      hipLaunchKernelGGL(abc_scatter_kernel, dim3(grid), dim3(256), 0, st, (const CoefRec*)recs.p, ncoef, 0u,
                          (const uint32_t*)row_ptr.p, (const uint32_t*)rank.p, (uint32_t*)sig.p, vals.p);
     }
     uint32_t herr = 0;

@@ -60,6 +60,11 @@ void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own
 void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k);  // builds twiddle tables (hipMalloc) once per k
 void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k);
 void ntt_natural(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
+// unscaled, unpermuted halves of a transform: DIF natural -> bit-reversed, DIT bit-reversed -> natural
+void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
+void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
+// H-scalar chain split over G ranks: the step between the two exchanges (ntt.hip.h, ntt_split_mid_kernel)
+void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h);
 void ntt_release(zkpoa_context* ctx);
 }  // namespace zkpoa
 

@@ -6,6 +6,12 @@ RCCL has no reduction operator for elliptic-curve addition, so the "all-reduce o
 all-gather + local add; the payload is a few hundred bytes, so the collective is latency-bound and
 bucket arrays are never exchanged. One process per GPU; `torch.distributed` (backend "nccl" = RCCL on
 ROCm, "gloo" in the CPU tests) provides the collective.
+
+The H-scalar chain (buildABC, 3 x ifft -> coset shift -> fft, joinABC) shards too (NTT row):
+every transform is a four-step NTT over world = G ranks with ONE all-to-all, i.e. two exchanges per
+polynomial for the whole chain, each rank sending n*32/G^2 bytes to every peer in a single hop (xGMI is
+point-to-point, so all 7 links carry their own pair concurrently; no ring). `split_h_chain` below runs the
+three local stages (C ABI zkpoa_split_stage1/2/3) around `dist.all_to_all_single`.
 """
 
 
@@ -50,3 +56,61 @@ def sharded_prove(compute_partials, header_points, sum_partials, assemble, r, s,
     every rank (the caller fixes them, e.g. rank 0 draws and broadcasts). Returns proof_points[256]."""
     parts = all_gather_bytes(compute_partials(), dist, device)
     return assemble(header_points, sum_partials(parts), r, s)
+
+
+def split_chain_supported(world, domain):
+    """The split H-scalar chain needs world in {2, 4, 8} and world^2 <= domain; otherwise the chain is replicated."""
+    return world in (2, 4, 8) and world * world <= domain
+
+
+def exchange(recv, send, dist=None, sync=None):
+    """One exchange of the split chain: for each of the 3 polynomials (dim 0 of the uint8 tensors, shape
+    [3, M*32]) an all-to-all with equal splits, so rank h receives slots [h*Q, (h+1)*Q) of every rank's
+    buffer, ordered by source rank. `sync` (e.g. torch.cuda.synchronize) runs after the collectives so the
+    next stage, which runs on the library's own stream, sees the data."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        recv.copy_(send)
+    elif send.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal only (ranks sharing a GPU, CPU process group): stage the exchange through the host
+        hs = send.cpu()
+        hr = hs.new_empty(hs.shape)
+        for x in range(hs.shape[0]):
+            dist.all_to_all_single(hr[x], hs[x])
+        recv.copy_(hr)
+    else:
+        for x in range(send.shape[0]):
+            dist.all_to_all_single(recv[x], send[x])
+    if sync is not None:
+        sync()
+
+
+def split_h_chain(stage1, stage2, stage3, buf_a, buf_b, dist=None, sync=None):
+    """The three local stages around the two exchanges. stageN take the buffers as the C ABI does:
+    stage1(out=buf_a); exchange a->b; stage2(in=buf_b, out=buf_a); exchange a->b; stage3(inout=buf_b).
+    After it the rank's H scalars live on its key handle (zkpoa_split_stage3)."""
+    stage1(buf_a)
+    exchange(buf_b, buf_a, dist, sync)
+    stage2(buf_b, buf_a)
+    exchange(buf_b, buf_a, dist, sync)
+    stage3(buf_b)
+
+
+def exchange_buffers(domain, world, device):
+    """The two exchange buffers of the split chain: 3 polynomials x (domain / world) x 32 B each."""
+    import torch
+    buf_a = torch.empty((3, domain // world * 32), dtype=torch.uint8, device=device)
+    return buf_a, torch.empty_like(buf_a)
+
+
+def sharded_prove_split(ctx, key, d_witness, header_points, sum_partials, assemble, r, s, dist, device, buffers=None):
+    """One Groth16 proof over world GPUs with the H-scalar chain split as well (key: a split shard handle,
+    load_zkey_shard_split / set_shard_split; d_witness: device pointer or None for the witness already on the
+    handle; buffers: exchange_buffers(...) kept across proofs). Returns proof_points[256], identical on every rank."""
+    import torch
+    buf_a, buf_b = buffers if buffers is not None else exchange_buffers(key.info()[2], dist.get_world_size(), device)
+    sync = torch.cuda.synchronize if buf_a.is_cuda else None
+    split_h_chain(lambda a: ctx.split_stage1(key, d_witness, a.data_ptr()),
+                  lambda b, a: ctx.split_stage2(key, b.data_ptr(), a.data_ptr()),
+                  lambda b: ctx.split_stage3(key, b.data_ptr()), buf_a, buf_b, dist, sync)
+    return sharded_prove(lambda: ctx.prove_partials_device(key, None), header_points, sum_partials, assemble, r, s,
+                         dist, device)
