@@ -210,6 +210,8 @@ def main():
         raise SystemExit("unknown workload " + args.workload)
     n_local = 1 << logn
     ctx = zk.Context(local_rank)
+    if os.environ.get("ZKPOA_MSM_C"):        # experiments only: force the Pippenger window width
+        ctx.set_option("msm_c", int(os.environ["ZKPOA_MSM_C"]))
     if logn > 27:
         raise SystemExit("msm workload limited to 2^27 points per GPU")
 

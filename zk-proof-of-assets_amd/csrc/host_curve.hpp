@@ -59,14 +59,18 @@ inline XYZZ<HF> h_mul(const XYZZ<HF>& p, const uint64_t k[4]) {
 
 // Horner over the per-window sums of one MSM: result = sum_w 2^(c*w) * S[w]
 template <class HF>
-inline XYZZ<HF> h_combine_windows(const void* window_sums, uint32_t W, uint32_t c) {
+inline XYZZ<HF> h_combine_windows(const void* window_sums, uint32_t W, uint32_t c, uint32_t logS) {
+  // window_sums: per window the pair (U, V) of the device's bucket reduction; window sum = 2^logS * U + V
   constexpr size_t X = 4 * HostBytes<HF>::N;
   const char* base = reinterpret_cast<const char*>(window_sums);
   XYZZ<HF> acc = XYZZ<HF>::inf();
   for (int w = (int)W - 1; w >= 0; w--) {
     for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
-    XYZZ<HF> s = h_xyzz_from_bytes<HF>(base + (size_t)w * X);
-    xyzz_add(acc, s);
+    XYZZ<HF> u = h_xyzz_from_bytes<HF>(base + (size_t)(2 * w) * X);
+    for (uint32_t k = 0; k < logS; k++) u = xyzz_dbl(u);
+    XYZZ<HF> v = h_xyzz_from_bytes<HF>(base + (size_t)(2 * w + 1) * X);
+    xyzz_add(acc, u);
+    xyzz_add(acc, v);
   }
   return acc;
 }

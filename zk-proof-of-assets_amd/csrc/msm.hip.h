@@ -38,7 +38,8 @@ struct MsmPlan {
   uint32_t TB = 0;  // total buckets
   uint32_t K0 = 0;  // level-0 piece length
   uint32_t K = 64;  // piece length for levels >= 1
-  static constexpr uint32_t SEG = 8;  // buckets per reduction segment
+  // bucket reduction: the Nb buckets of a window form a rows x S matrix, b = hi * S + lo
+  uint32_t logS = 0, logRows = 0;
 };
 
 inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
@@ -60,6 +61,8 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
   p.W = (254 + p.c - 1) / p.c;
   p.Nb = 1u << (p.c - 1);
   p.TB = p.W * p.Nb;
+  p.logS = (uint32_t)(p.c - 1 + 1) / 2;
+  p.logRows = (uint32_t)(p.c - 1) - p.logS;
   double avg = (double)n / (double)p.Nb;
   uint32_t k0 = 32;
   while (k0 < 2 * avg && k0 < 512) k0 <<= 1;
@@ -375,6 +378,7 @@ static __global__ __launch_bounds__(256) void msm_accumN_kernel(const void* __re
 }
 
 // ---- 5: bucket reduction ----------------------------------------------------------------------
+constexpr uint32_t kReduceLogParts = 4;   // threads per row / column sum (each adds len / 16 buckets, then an LDS tree)
 template <class F>
 __device__ __noinline__ void xyzz_add_ni(XYZZ<F>& a, const XYZZ<F>& b) {
   xyzz_add(a, b);
@@ -384,34 +388,72 @@ __device__ __noinline__ void xyzz_dbl_ni(XYZZ<F>& a) {
   a = xyzz_dbl(a);
 }
 
-// thread g: segment of SEG buckets [g*SEG, +SEG) inside window g / (Nb/SEG).
-// X[g] = sum_j (j+1) * B[g*SEG+j]  +  (gw*SEG) * sum_j B[g*SEG+j],   gw = segment index in its window.
+// Window sum = sum_b (b + 1) * B_b. With b = hi * S + lo (rows x S matrix of the window's buckets):
+//   sum_b (b + 1) B_b = S * sum_hi hi * R_hi + sum_lo (lo + 1) * C_lo,   R_hi = row sums, C_lo = column sums.
+// All 2 * Nb additions of the row / column sums are independent short chains (PARTS threads per sum, T terms
+// each, then an LDS tree over the parts), the weights are <= max(logS, logRows) bits (double-and-add per sum),
+// and the two weighted totals U = sum hi R_hi, V = sum (lo+1) C_lo per window go to the host, which forms
+// 2^logS * U + V. Compared with a running sum per segment this halves the group operations and has no long
+// dependent chain (a 2^20 MSM has only 17 x 2^14 buckets: latency, not throughput, decides).
+// out[(w * 2 + grp) * E + idx]: grp 0 = R (idx = hi < rows), grp 1 = C (idx = lo < S); E >= max(rows, S).
 template <class F>
-static __global__ __launch_bounds__(256) void msm_reduce_seg_kernel(const void* __restrict__ buckets, uint32_t TB,
-                                                             uint32_t Nb, void* __restrict__ X) {
-  constexpr uint32_t SEG = MsmPlan::SEG;
-  uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  if (g >= TB / SEG) return;
-  uint32_t segs_per_window = Nb / SEG;
-  uint32_t gw = g % segs_per_window;
-  XYZZ<F> acc = XYZZ<F>::inf(), wt = XYZZ<F>::inf();
-  for (int j = (int)SEG - 1; j >= 0; j--) {
-    XYZZ<F> bkt = load_xyzz<F>(buckets, (size_t)g * SEG + j);
-    xyzz_add_ni(acc, bkt);
-    xyzz_add_ni(wt, acc);
-  }
-  // wt += (gw*SEG) * acc, MSB-first double-and-add
-  uint32_t k = gw * SEG;
-  if (k != 0 && !acc.is_inf()) {
-    XYZZ<F> r = acc;
-    int top = 31 - __builtin_clz(k);
-    for (int bit = top - 1; bit >= 0; bit--) {
-      xyzz_dbl_ni(r);
-      if ((k >> bit) & 1u) xyzz_add_ni(r, acc);
+static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void* __restrict__ buckets, uint32_t W,
+                                                                     uint32_t Nb, uint32_t logS, uint32_t logRows,
+                                                                     uint32_t logParts, uint32_t E,
+                                                                     void* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t parts = 1u << logParts, part = gid & (parts - 1u), o = gid >> logParts;
+  const uint32_t S = 1u << logS, rows = 1u << logRows, per_window = rows + S;
+  const uint32_t w = o / per_window, r = o % per_window;
+  const bool valid = w < W;
+  const bool is_row = r < rows;
+  const uint32_t idx = is_row ? r : r - rows;
+  const uint32_t len = is_row ? S : rows, stride = is_row ? 1u : S;
+  const size_t base = (size_t)w * Nb + (is_row ? (size_t)idx * S : (size_t)idx);
+  const uint32_t per = len >> logParts;   // logParts <= min(logS, logRows)
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (valid) {
+    for (uint32_t j = part * per; j < (part + 1u) * per; j++) {
+      XYZZ<F> bkt = load_xyzz<F>(buckets, base + (size_t)j * stride);
+      xyzz_add_ni(acc, bkt);
     }
-    xyzz_add_ni(wt, r);
   }
-  store_xyzz(X, g, wt);
+  for (uint32_t st = parts >> 1; st > 0; st >>= 1) {
+    store_xyzz(lds_raw, threadIdx.x, acc);
+    __syncthreads();
+    if (part < st) {
+      XYZZ<F> o2 = load_xyzz<F>(lds_raw, threadIdx.x + st);
+      xyzz_add_ni(acc, o2);
+    }
+    __syncthreads();
+  }
+  if (valid && part == 0) store_xyzz(out, ((size_t)w * 2u + (is_row ? 0u : 1u)) * E + idx, acc);
+}
+
+// X[(w*2+grp)*E + idx] <- weight * X[...]: weight = idx for row sums, idx + 1 for column sums; padding
+// entries (idx >= rows resp. S) become the neutral element. MSB-first double-and-add.
+template <class F>
+static __global__ __launch_bounds__(256) void msm_bucket_weight_kernel(void* __restrict__ X, uint32_t logS,
+                                                                       uint32_t logRows, uint32_t E, uint32_t total) {
+  uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  uint32_t grp = (gid / E) & 1u, idx = gid % E;
+  uint32_t cnt = grp ? (1u << logS) : (1u << logRows);
+  uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
+  XYZZ<F> r = XYZZ<F>::inf();
+  if (k) {
+    XYZZ<F> v = load_xyzz<F>(X, gid);
+    if (!v.is_inf()) {
+      r = v;
+      int top = 31 - __builtin_clz(k);
+      for (int bit = top - 1; bit >= 0; bit--) {
+        xyzz_dbl_ni(r);
+        if ((k >> bit) & 1u) xyzz_add_ni(r, v);
+      }
+    }
+  }
+  store_xyzz(X, gid, r);
 }
 
 // Y[w][blockIdx.x] = sum of X[w][blockIdx.x*256 .. +256) (S entries per window), LDS tree.
@@ -486,7 +528,7 @@ inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
   size_t T = (size_t)p.n * p.W;
   size_t p1 = T / p.K0 + p.TB + 1;
   size_t p2 = p1 / 2 + 1;
-  size_t segs = p.TB / MsmPlan::SEG;
+  size_t E = (size_t)1 << p.logS;   // logS >= logRows
   size_t bytes = 0;
   bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // po_b, po_c
   bytes += al256(((size_t)p.TB / kScanTile + 2) * 4);
@@ -494,8 +536,8 @@ inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
   bytes += al256((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
   bytes += al256(p1 * MsmSizes<F>::kXyzz);            // P1
   bytes += al256(p2 * MsmSizes<F>::kXyzz);            // P2
-  bytes += al256(segs * MsmSizes<F>::kXyzz);          // X
-  bytes += al256((segs / 256 + p.W) * MsmSizes<F>::kXyzz) * 2;
+  bytes += al256(2 * p.W * E * MsmSizes<F>::kXyzz);                    // X: row / column sums
+  bytes += al256(2 * p.W * ((E + 255) / 256) * MsmSizes<F>::kXyzz) * 2;  // tree-sum levels
   return bytes + (1 << 12);
 }
 
@@ -587,7 +629,8 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
 // Phase B on lane.stream for base array d_bases. `own_arena`: true when `sr` was produced on this lane
 // by the immediately preceding msm_sort_phase (the accumulation buffers are then taken after it);
 // false when `sr` lives on another lane (that lane's stream must have finished phase A): this lane's arena
-// is reset and only holds the accumulation buffers. On return window_sums_host = W XYZZ window sums.
+// is reset and only holds the accumulation buffers. On return window_sums_host = 2 W XYZZ: per window the
+// weighted row total U and column total V (window sum = 2^logS * U + V, formed by h_combine_windows).
 template <class F>
 inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases, void* window_sums_host,
                             bool own_arena, float* accum_ms = nullptr) {
@@ -608,12 +651,12 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   size_t p2_cap = p1_cap / 2 + 1;
   char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
   char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
-  const uint32_t segs = p.TB / MsmPlan::SEG;
-  const uint32_t S0 = p.Nb / MsmPlan::SEG;
-  char* X = ws.take<char>((size_t)segs * MsmSizes<F>::kXyzz);
-  const uint32_t S1 = (S0 + 255) / 256;
-  char* Y1 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
-  char* Y2 = ws.take<char>((size_t)(S1 * p.W) * MsmSizes<F>::kXyzz);
+  const uint32_t E = 1u << p.logS;            // entries per (window, row|column) group; logS >= logRows
+  const uint32_t groups = 2u * p.W;
+  char* X = ws.take<char>((size_t)groups * E * MsmSizes<F>::kXyzz);
+  const uint32_t S1 = (E + 255) / 256;
+  char* Y1 = ws.take<char>((size_t)(S1 * groups) * MsmSizes<F>::kXyzz);
+  char* Y2 = ws.take<char>((size_t)(S1 * groups) * MsmSizes<F>::kXyzz);
 
   ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
   if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
@@ -646,26 +689,34 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
     std::swap(Pin, Pout);
     std::swap(cap_in, cap_out);
   }
-  // bucket reduction
-  hipLaunchKernelGGL((msm_reduce_seg_kernel<F>), dim3((segs + 255) / 256), dim3(256), 0, st, (const void*)buckets, p.TB,
-                     p.Nb, (void*)X);
+  // bucket reduction: row / column sums, weights, totals per (window, group)
+  {
+    uint32_t log_parts = p.logRows < kReduceLogParts ? p.logRows : kReduceLogParts;
+    uint64_t threads = ((uint64_t)p.W << log_parts) * ((1u << p.logRows) + E);
+    hipLaunchKernelGGL((msm_bucket_sums_kernel<F>), dim3((uint32_t)((threads + 255) / 256)), dim3(256),
+                       256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.W, p.Nb, p.logS, p.logRows, log_parts, E,
+                       (void*)X);
+    uint32_t total = groups * E;
+    hipLaunchKernelGGL((msm_bucket_weight_kernel<F>), dim3((total + 255) / 256), dim3(256), 0, st, (void*)X, p.logS,
+                       p.logRows, E, total);
+  }
   const char* cur = X;
-  uint32_t S = S0;
+  uint32_t S = E;
   char* ybuf[2] = {Y1, Y2};
   int yi = 0;
   while (true) {
     uint32_t S_out = (S + 255) / 256;
-    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, p.W), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, groups), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
                        (const void*)cur, S, S_out, (void*)ybuf[yi]);
     cur = ybuf[yi];
     yi ^= 1;
     S = S_out;
     if (S == 1) break;
   }
-  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)p.W * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)groups * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
-  memcpy(window_sums_host, lane.pinned, (size_t)p.W * MsmSizes<F>::kXyzz);
+  memcpy(window_sums_host, lane.pinned, (size_t)groups * MsmSizes<F>::kXyzz);
   if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));
 }
 

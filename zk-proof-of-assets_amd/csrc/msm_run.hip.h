@@ -21,7 +21,7 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
     ms2[0] = tot;
     ms2[1] = acc_ms;
   }
-  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.W, p.c);
+  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.W, p.c, p.logS);
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }
 
@@ -43,7 +43,7 @@ void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool ow
     ms2[0] = tot;
     ms2[1] = acc_ms;
   }
-  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.W, sr.p.c);
+  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.W, sr.p.c, sr.p.logS);
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }
 
