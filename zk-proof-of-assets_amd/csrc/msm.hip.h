@@ -37,7 +37,8 @@ struct MsmPlan {
   uint32_t Nb = 0;  // buckets per window = 2^(c-1)
   uint32_t TB = 0;  // total buckets
   uint32_t K0 = 0;  // level-0 piece length
-  uint32_t K = 64;  // piece length for levels >= 1
+  uint32_t K = 4;   // fan-in per thread for levels >= 1: hot buckets (witness bits) are latency-bound chains of full
+                    // additions, so a small fan-in with more levels beats 64 sequential additions per thread
   // bucket reduction: the Nb buckets of a window form a rows x S matrix, b = hi * S + lo
   uint32_t logS = 0, logRows = 0;
 };
@@ -378,7 +379,8 @@ static __global__ __launch_bounds__(256) void msm_accumN_kernel(const void* __re
 }
 
 // ---- 5: bucket reduction ----------------------------------------------------------------------
-constexpr uint32_t kReduceLogParts = 4;   // threads per row / column sum (each adds len / 16 buckets, then an LDS tree)
+constexpr uint32_t kReduceLogParts = 4;   // threads per row / column sum (each adds len / 16 buckets, then an LDS tree;
+                                          // 8..32 measured alike, 64 slower)
 template <class F>
 __device__ __noinline__ void xyzz_add_ni(XYZZ<F>& a, const XYZZ<F>& b) {
   xyzz_add(a, b);
@@ -512,10 +514,12 @@ inline size_t msm_sort_workspace_bytes(const MsmPlan& p) {
   bytes += al256((size_t)p.TB * 4);                  // counts
   bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // off0, po_a
   bytes += al256(T * 4) * 2;                         // digits, sorted
-  bytes += al256(T * 8);                             // coarse-sorted entries
-  bytes += al256(((size_t)sp.SB + 1) * 4) * 3;       // bin_cnt, bin_off, tpo
-  bytes += al256((size_t)sp.chunks1 * sp.W * sp.bins * 4);
-  bytes += al256((size_t)sp.tasks2_max * sp.F * 4);
+  if (sp.npass > 1) bytes += al256(T * 8);           // entries between passes (ping)
+  if (sp.npass > 2) bytes += al256(T * 8);           // (pong)
+  for (uint32_t l = 0; l < sp.npass; l++) {
+    if (l + 1 < sp.npass) bytes += al256(((size_t)sp.segs[l + 1] + 1) * 4) * 3;   // seg_cnt, seg_off, tpo
+    bytes += al256((size_t)sp.tasks_max[l] * ((size_t)1 << sp.bits[l]) * 4);       // base
+  }
   bytes += al256(((size_t)p.TB / kScanTile + 2) * 4);
   bytes += al256(64);
   bytes += al256(p1 * 4) * 3;                        // pbkt, plen, order
@@ -568,12 +572,18 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   sr.off0 = ws.take<uint32_t>(p.TB + 1);
   sr.po_a = ws.take<uint32_t>(p.TB + 1);
   uint32_t* digits = ws.take<uint32_t>(T_max);
-  uint2* coarse = ws.take<uint2>(T_max);
-  uint32_t* bin_cnt = ws.take<uint32_t>(sp.SB + 1);
-  uint32_t* bin_off = ws.take<uint32_t>(sp.SB + 1);
-  uint32_t* tpo = ws.take<uint32_t>(sp.SB + 1);
-  uint32_t* base1 = ws.take<uint32_t>((size_t)sp.chunks1 * sp.W * sp.bins);
-  uint32_t* base2 = ws.take<uint32_t>((size_t)sp.tasks2_max * sp.F);
+  uint2* ebuf[2] = {sp.npass > 1 ? ws.take<uint2>(T_max) : nullptr, sp.npass > 2 ? ws.take<uint2>(T_max) : nullptr};
+  // per pass: output segment counts / offsets / task offsets (the last pass writes the bucket arrays) and bases
+  uint32_t *seg_cnt[kSortMaxPasses] = {}, *seg_off[kSortMaxPasses] = {}, *seg_tpo[kSortMaxPasses] = {},
+           *base[kSortMaxPasses] = {};
+  for (uint32_t l = 0; l < sp.npass; l++) {
+    if (l + 1 < sp.npass) {
+      seg_cnt[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
+      seg_off[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
+      seg_tpo[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
+    }
+    base[l] = ws.take<uint32_t>((size_t)sp.tasks_max[l] << sp.bits[l]);
+  }
   sr.sorted = ws.take<uint32_t>(T_max);
   uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
   uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
@@ -587,28 +597,44 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   ZK_HIP(hipMemsetAsync(sr.counts, 0, (size_t)p.TB * 4, st));
   ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
   ZK_HIP(hipMemsetAsync(len_hist, 0, 2 * (kMaxPieceLen + 1) * 4, st));
-  ZK_HIP(hipMemsetAsync(bin_cnt, 0, ((size_t)sp.SB + 1) * 4, st));
+  for (uint32_t l = 0; l + 1 < sp.npass; l++)
+    ZK_HIP(hipMemsetAsync(seg_cnt[l], 0, ((size_t)sp.segs[l + 1] + 1) * 4, st));
   const uint32_t nblk = (p.n + 255) / 256;
-  if (p.n) {
-    hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
-    hipLaunchKernelGGL((msm_sort_coarse_kernel<false>), dim3(sp.chunks1, sp.W), dim3(256), 0, st,
-                       (const uint32_t*)digits, sp, bin_cnt, (const uint32_t*)bin_off, base1, coarse);
-  }
-  scan_u32(st, bin_cnt, sp.SB, 0, 0, bin_off, block_sums, misc + 4, nullptr);
-  scan_u32(st, bin_cnt, sp.SB, 1, sp.CH2, tpo, block_sums, misc + 5, nullptr);
-  if (p.n) {
-    hipLaunchKernelGGL((msm_sort_coarse_kernel<true>), dim3(sp.chunks1, sp.W), dim3(256), 0, st,
-                       (const uint32_t*)digits, sp, bin_cnt, (const uint32_t*)bin_off, base1, coarse);
-    hipLaunchKernelGGL((msm_sort_fine_kernel<false>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
-                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, sr.counts,
-                       (const uint32_t*)sr.off0, base2, sr.sorted);
-  }
-  scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
-  scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
-  if (p.n) {
-    hipLaunchKernelGGL((msm_sort_fine_kernel<true>), dim3((uint32_t)sp.tasks2_max), dim3(256), 0, st,
-                       (const uint2*)coarse, sp, (const uint32_t*)bin_off, (const uint32_t*)tpo, sr.counts,
-                       (const uint32_t*)sr.off0, base2, sr.sorted);
+  if (p.n) hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
+  for (uint32_t l = 0; l < sp.npass; l++) {
+    const bool first = l == 0, last = l + 1 == sp.npass;
+    const uint2* in = first ? nullptr : ebuf[(l - 1) & 1];
+    uint2* out = last ? nullptr : ebuf[l & 1];
+    const uint32_t* in_off = first ? nullptr : seg_off[l - 1];
+    const uint32_t* tpo = first ? nullptr : seg_tpo[l - 1];
+    uint32_t* out_cnt = last ? sr.counts : seg_cnt[l];
+    uint32_t* out_off = last ? sr.off0 : seg_off[l];
+    const dim3 grid = first ? dim3(sp.chunks0, sp.W) : dim3((uint32_t)sp.tasks_max[l]);
+    if (p.n) {
+      if (first)
+        hipLaunchKernelGGL((msm_sort_count_kernel<true>), grid, dim3(256), 0, st, sp, l, (const uint32_t*)digits, in,
+                           in_off, tpo, out_cnt, base[l]);
+      else
+        hipLaunchKernelGGL((msm_sort_count_kernel<false>), grid, dim3(256), 0, st, sp, l, (const uint32_t*)digits, in,
+                           in_off, tpo, out_cnt, base[l]);
+    }
+    if (last) {
+      scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
+      scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
+    } else {
+      scan_u32(st, seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], block_sums, misc + 4 + 2 * l, nullptr);
+      scan_u32(st, seg_cnt[l], sp.segs[l + 1], 1, sp.CH, seg_tpo[l], block_sums, misc + 5 + 2 * l, nullptr);
+    }
+    if (p.n) {
+#define ZK_SORT_SCATTER(F_, L_)                                                                                       \
+  hipLaunchKernelGGL((msm_sort_scatter_kernel<F_, L_>), grid, dim3(256), 0, st, sp, l, (const uint32_t*)digits, in,  \
+                     in_off, tpo, (const uint32_t*)out_off, (const uint32_t*)base[l], out, sr.sorted)
+      if (first && last) ZK_SORT_SCATTER(true, true);
+      else if (first) ZK_SORT_SCATTER(true, false);
+      else if (last) ZK_SORT_SCATTER(false, true);
+      else ZK_SORT_SCATTER(false, false);
+#undef ZK_SORT_SCATTER
+    }
   }
   uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
   ZK_HIP(hipMemcpyAsync(hb, misc, 16, hipMemcpyDeviceToHost, st));

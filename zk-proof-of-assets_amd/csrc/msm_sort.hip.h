@@ -1,50 +1,65 @@
-// Bucket sort of the MSM's (point, window) entries: two-level MSD counting sort on LDS histograms.
+// Bucket sort of the MSM's (point, window) entries: MSD counting sort in passes of <= 8 key bits, every
+// pass staged through LDS so that HBM only sees coalesced runs.
 //
-// Replaces the first version's per-entry global atomics (one returning atomic + a 4-byte rank per
-// entry, ~50 % of a 2^26 MSM). Every (window, bucket) list of point indices is produced with:
-//   K0 digits   : scalar -> W signed digits (mag | sign<<31), written once, window-major.
-//   level 1     : bucket id split as (coarse bin : fine key), fine = low FB bits.
-//     K1        : task = (chunk of points, window): LDS histogram over coarse bins; ONE global atomic
-//                 per (task, non-empty bin) reserves the task's slice of that bin  -> base1
-//     scan      : bin totals -> bin offsets; ceil(size / CH2) -> level-2 task offsets
-//     K3        : same tasks: LDS cursors = bin offset + base1; entries (idx|sign, fine) scattered
-//                 to their bin (ranks from LDS atomics; wave-ballot aggregation of the leading key)
-//   level 2     : task = (bin, split of <= CH2 entries): bins of any size stay load-balanced
-//     K4a       : LDS histogram over fine keys; one global atomic per (task, key) into the bucket counts
-//     scan      : bucket counts -> bucket offsets (off0), piece offsets
-//     K4b       : LDS cursors = off0 + base2; point indices scattered into their bucket's list
-// HBM traffic ~40 B per entry, all atomics except O(tasks x bins) of them are LDS atomics. Order inside a
-// bucket is arbitrary, which the (commutative) bucket sum does not see.
+// Replaces the first version's per-entry global atomics (one returning atomic + a 4-byte rank per entry,
+// ~50 % of a 2^26 MSM) and the second version's two unstaged scatter passes (2048 bins + 256 keys: every
+// lane stored to its own cache line, ~100 G stores/s whatever the bin count, 25 of 108 ms at 2^26).
+// Every (window, bucket) list of point indices is produced with:
+//   K0 digits : scalar -> W signed digits (mag | sign<<31), written once, window-major.
+//   pass l    : the bucket id (c-1 bits) is consumed from the top, bits[l] <= 8 bits per pass (2 passes up
+//               to 16 bits, 3 up to 21: 7 + 6 + 6 at c = 20). Input of pass l is partitioned into segments (pass 0: one per window;
+//               later: one per (window, key prefix)); a task is <= CH entries of one segment.
+//     count   : LDS histogram of the task over the 2^bits[l] bins, ONE global atomic per (task, non-empty bin)
+//               reserves the task's slice of the output segment -> base
+//     scan    : segment totals -> output segment offsets, ceil(size / CH) -> task offsets of the next pass
+//     scatter : per tile of 2048 entries: LDS histogram + ranks (wave-ballot aggregation of the leading key,
+//               so a hot bucket costs one LDS atomic per wave), exclusive scan of the tile histogram, entries
+//               written to LDS grouped by bin, then copied out with consecutive lanes on consecutive
+//               addresses of each bin's run (avg >= 16 entries = 128-256 B per (tile, bin)).
+//   The last pass writes the 4-byte point index | sign only; its segment offsets are the bucket offsets.
+// HBM traffic ~12-16 B per entry and pass; all atomics except O(tasks x bins) of them are LDS atomics. Order
+// inside a bucket is arbitrary, which the (commutative) bucket sum does not see.
 #pragma once
 // included from msm.hip.h after the scalar-recoding helpers, the u32 scan and find_bucket
 #include "bn254_field.hip.h"
 
 namespace zkpoa {
 
+constexpr uint32_t kSortMaxBits = 8;                 // key bits per pass (one bin per thread of the workgroup)
+constexpr uint32_t kSortMaxBins = 1u << kSortMaxBits;
+constexpr uint32_t kSortEpt = 8;                     // entries per thread and tile
+constexpr uint32_t kSortTile = 256u * kSortEpt;      // 2048 entries = 16 KiB of LDS staging
+constexpr uint32_t kSortMaxPasses = 3;
+
 struct SortPlan {
   uint32_t n, W, c, Nb;
-  uint32_t FB, F;        // fine bits / keys per bin
-  uint32_t bins;         // coarse bins per window
-  uint32_t SB;           // W * bins
-  uint32_t CH1, chunks1; // level-1 task size / tasks per window
-  uint32_t CH2;          // level-2 task size
-  uint64_t tasks2_max;
+  uint32_t npass;
+  uint32_t bits[kSortMaxPasses];    // key bits consumed by pass l (from the top)
+  uint32_t rem[kSortMaxPasses];     // key bits still in the entry when pass l starts (rem[0] = c - 1)
+  uint32_t segs[kSortMaxPasses + 1];// segments entering pass l; segs[npass] = W * Nb buckets
+  uint32_t CH;                      // task size (entries)
+  uint32_t chunks0;                 // pass-0 tasks per window
+  uint64_t tasks_max[kSortMaxPasses];
 };
 
 inline SortPlan make_sort_plan(uint32_t n, uint32_t W, uint32_t c) {
-  SortPlan s;
+  SortPlan s{};
   s.n = n; s.W = W; s.c = c; s.Nb = 1u << (c - 1);
-  uint32_t tb = c - 1;
-  uint32_t cb = tb > 8 ? tb - 8 : 0;
-  if (cb > 11) cb = 11;
-  s.FB = tb - cb;
-  s.F = 1u << s.FB;
-  s.bins = 1u << cb;
-  s.SB = W * s.bins;
-  s.CH1 = n > (1u << 22) ? (1u << 16) : (1u << 14);
-  s.chunks1 = n ? (n + s.CH1 - 1) / s.CH1 : 1;
-  s.CH2 = 1u << 14;
-  s.tasks2_max = ((uint64_t)n * W) / s.CH2 + s.SB + 1;
+  const uint32_t tb = c - 1;
+  s.npass = tb <= kSortMaxBits ? 1u : (tb + kSortMaxBits - 1) / kSortMaxBits;
+  uint32_t left = tb;
+  s.segs[0] = W;
+  for (uint32_t l = 0; l < s.npass; l++) {
+    uint32_t passes_left = s.npass - l;
+    s.bits[l] = (left + passes_left - 1) / passes_left;
+    s.rem[l] = left;
+    left -= s.bits[l];
+    s.segs[l + 1] = s.segs[l] << s.bits[l];
+  }
+  s.CH = 8u * kSortTile;   // 16384 entries per task
+  s.chunks0 = n ? (n + s.CH - 1) / s.CH : 1;
+  s.tasks_max[0] = (uint64_t)s.chunks0 * W;
+  for (uint32_t l = 1; l < s.npass; l++) s.tasks_max[l] = ((uint64_t)n * W) / s.CH + s.segs[l] + 1;
   return s;
 }
 
@@ -94,80 +109,152 @@ static __global__ __launch_bounds__(256) void msm_digits_kernel(const void* __re
   }
 }
 
-// ---- level 1 ---------------------------------------------------------------------------------------------
-constexpr uint32_t kMaxBins = 2048;
+// ---- one pass ------------------------------------------------------------------------------------------
+// Task geometry. FIRST: task = (chunk blockIdx.x, window blockIdx.y) of the digit array; otherwise task
+// t = blockIdx.x over the segments of `in_off` with task offsets `tpo`. Returns false when the block has no task.
+struct SortTask {
+  uint32_t seg, start, end;
+  size_t id;
+};
 
-template <bool SCATTER>
-static __global__ __launch_bounds__(256) void msm_sort_coarse_kernel(const uint32_t* __restrict__ digits, SortPlan sp,
-                                                                     uint32_t* __restrict__ bin_cnt,
-                                                                     const uint32_t* __restrict__ bin_off,
-                                                                     uint32_t* __restrict__ base1,
-                                                                     uint2* __restrict__ coarse) {
-  __shared__ uint32_t h[kMaxBins];
-  const uint32_t w = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const size_t task = (size_t)w * sp.chunks1 + chunk;
-  for (uint32_t b = tid; b < sp.bins; b += 256u)
-    h[b] = SCATTER ? bin_off[w * sp.bins + b] + base1[task * sp.bins + b] : 0u;
-  __syncthreads();
-  const uint32_t start = chunk * sp.CH1;
-  const uint32_t end = (sp.n - start) < sp.CH1 ? sp.n : start + sp.CH1;
-  const uint32_t fmask = sp.F - 1u;
-  for (uint32_t off = 0; off < sp.CH1; off += 256u) {
-    uint32_t i = start + off + tid;
-    bool valid = i < end;
-    uint32_t d = valid ? digits[(size_t)w * sp.n + i] : 0u;
-    uint32_t mag = d & 0x7fffffffu;
-    valid = valid && mag != 0;
-    uint32_t key = valid ? (mag - 1u) >> sp.FB : 0u;
-    uint32_t pos = lds_count_rank(h, key, valid);
-    if (SCATTER && valid) coarse[pos] = make_uint2(i | (d & 0x80000000u), (mag - 1u) & fmask);
-    if (start + off + 256u >= end) break;    // uniform: the remaining iterations have no valid lane
+template <bool FIRST>
+ZK_DEV bool sort_task(const SortPlan& sp, uint32_t pass, const uint32_t* __restrict__ in_off,
+                      const uint32_t* __restrict__ tpo, SortTask& t) {
+  if (FIRST) {
+    t.seg = blockIdx.y;
+    t.id = (size_t)blockIdx.y * sp.chunks0 + blockIdx.x;
+    t.start = blockIdx.x * sp.CH;
+    t.end = (sp.n - t.start) < sp.CH ? sp.n : t.start + sp.CH;   // indices inside the window's digit row
+    return true;
   }
-  if (!SCATTER) {
-    __syncthreads();
-    for (uint32_t b = tid; b < sp.bins; b += 256u) {
-      uint32_t cnt = h[b];
-      base1[task * sp.bins + b] = cnt ? atomicAdd(&bin_cnt[w * sp.bins + b], cnt) : 0u;
-    }
+  const uint32_t S = sp.segs[pass];
+  if (blockIdx.x >= tpo[S]) return false;
+  t.seg = find_bucket(tpo, S, blockIdx.x);
+  t.id = blockIdx.x;
+  t.start = in_off[t.seg] + (blockIdx.x - tpo[t.seg]) * sp.CH;
+  t.end = in_off[t.seg + 1];
+  if (t.end - t.start > sp.CH) t.end = t.start + sp.CH;
+  return true;
+}
+
+// entry e of the task's input -> (payload = point index | sign << 31, key = remaining bucket bits); false = skip
+template <bool FIRST>
+ZK_DEV bool sort_load(const SortPlan& sp, const uint32_t* __restrict__ digits, const uint2* __restrict__ in,
+                      const SortTask& t, uint32_t e, uint32_t& payload, uint32_t& key) {
+  payload = 0;
+  key = 0;
+  if (e >= t.end) return false;
+  if (FIRST) {
+    uint32_t d = digits[(size_t)t.seg * sp.n + e];
+    uint32_t mag = d & 0x7fffffffu;
+    payload = e | (d & 0x80000000u);
+    key = mag - 1u;
+    return mag != 0;
+  }
+  uint2 v = in[e];
+  payload = v.x;
+  key = v.y;
+  return true;
+}
+
+// count: base[task][bin] = this task's offset inside output segment (seg, bin)
+template <bool FIRST>
+static __global__ __launch_bounds__(256) void msm_sort_count_kernel(SortPlan sp, uint32_t pass,
+                                                                    const uint32_t* __restrict__ digits,
+                                                                    const uint2* __restrict__ in,
+                                                                    const uint32_t* __restrict__ in_off,
+                                                                    const uint32_t* __restrict__ tpo,
+                                                                    uint32_t* __restrict__ out_cnt,
+                                                                    uint32_t* __restrict__ base) {
+  __shared__ uint32_t h[kSortMaxBins];
+  SortTask t;
+  if (!sort_task<FIRST>(sp, pass, in_off, tpo, t)) return;
+  const uint32_t tid = threadIdx.x, nb = 1u << sp.bits[pass], shift = sp.rem[pass] - sp.bits[pass];
+  if (tid < nb) h[tid] = 0;
+  __syncthreads();
+  for (uint32_t off = t.start; off < t.end; off += 256u) {
+    uint32_t payload, key;
+    bool valid = sort_load<FIRST>(sp, digits, in, t, off + tid, payload, key);
+    (void)lds_count_rank(h, key >> shift, valid);
+  }
+  __syncthreads();
+  if (tid < nb) {
+    uint32_t cnt = h[tid];
+    base[t.id * nb + tid] = cnt ? atomicAdd(&out_cnt[(size_t)t.seg * nb + tid], cnt) : 0u;
   }
 }
 
-// ---- level 2 ---------------------------------------------------------------------------------------------
-constexpr uint32_t kMaxFine = 1024;
-
-template <bool SCATTER>
-static __global__ __launch_bounds__(256) void msm_sort_fine_kernel(const uint2* __restrict__ coarse, SortPlan sp,
-                                                                   const uint32_t* __restrict__ bin_off,
-                                                                   const uint32_t* __restrict__ tpo,
-                                                                   uint32_t* __restrict__ cnt0,
-                                                                   const uint32_t* __restrict__ off0,
-                                                                   uint32_t* __restrict__ base2,
-                                                                   uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t h[kMaxFine];
-  const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  if (t >= tpo[sp.SB]) return;
-  const uint32_t sb = find_bucket(tpo, sp.SB, t);
-  const uint32_t j = t - tpo[sb];
-  const uint32_t start = bin_off[sb] + j * sp.CH2;
-  uint32_t end = bin_off[sb + 1];
-  if (end - start > sp.CH2) end = start + sp.CH2;
-  const size_t kb = (size_t)sb * sp.F;       // first bucket of this bin (global bucket index)
-  for (uint32_t k = tid; k < sp.F; k += 256u) h[k] = SCATTER ? off0[kb + k] + base2[(size_t)t * sp.F + k] : 0u;
+// scatter. LAST: the output is the 4-byte payload at its final (bucket-sorted) position, else (payload, key
+// without the consumed bits) in the next pass's segment.
+template <bool FIRST, bool LAST>
+static __global__ __launch_bounds__(256) void msm_sort_scatter_kernel(SortPlan sp, uint32_t pass,
+                                                                      const uint32_t* __restrict__ digits,
+                                                                      const uint2* __restrict__ in,
+                                                                      const uint32_t* __restrict__ in_off,
+                                                                      const uint32_t* __restrict__ tpo,
+                                                                      const uint32_t* __restrict__ out_off,
+                                                                      const uint32_t* __restrict__ base,
+                                                                      uint2* __restrict__ out,
+                                                                      uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t hist[kSortMaxBins], toff[kSortMaxBins + 1], gpos[kSortMaxBins], cur[kSortMaxBins];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint2 stage[kSortTile];
+  SortTask t;
+  if (!sort_task<FIRST>(sp, pass, in_off, tpo, t)) return;
+  const uint32_t tid = threadIdx.x, nb = 1u << sp.bits[pass], shift = sp.rem[pass] - sp.bits[pass];
+  const uint32_t keymask = (1u << shift) - 1u;
+  static_assert(kSortMaxBins == 256, "one bin per thread");
+  cur[tid] = tid < nb ? out_off[(size_t)t.seg * nb + tid] + base[t.id * nb + tid] : 0u;
+  hist[tid] = 0;
   __syncthreads();
-  for (uint32_t off = 0; off < sp.CH2; off += 256u) {
-    uint32_t e = start + off + tid;
-    bool valid = e < end;
-    uint2 v = valid ? coarse[e] : make_uint2(0u, 0u);
-    uint32_t pos = lds_count_rank(h, v.y, valid);
-    if (SCATTER && valid) sorted[pos] = v.x;
-    if (start + off + 256u >= end) break;    // uniform: the remaining iterations have no valid lane
-  }
-  if (!SCATTER) {
-    __syncthreads();
-    for (uint32_t k = tid; k < sp.F; k += 256u) {
-      uint32_t cnt = h[k];
-      base2[(size_t)t * sp.F + k] = cnt ? atomicAdd(&cnt0[kb + k], cnt) : 0u;
+  for (uint32_t tile = t.start; tile < t.end; tile += kSortTile) {
+    uint32_t payload[kSortEpt], key[kSortEpt], rank[kSortEpt];
+    bool valid[kSortEpt];
+#pragma unroll
+    for (uint32_t e = 0; e < kSortEpt; e++) {
+      valid[e] = sort_load<FIRST>(sp, digits, in, t, tile + e * 256u + tid, payload[e], key[e]);
+      rank[e] = lds_count_rank(hist, key[e] >> shift, valid[e]);
     }
+    __syncthreads();
+    // exclusive scan of the tile histogram (one bin per thread, shuffle scan per wave), advance the run cursors
+    {
+      uint32_t v = hist[tid], x = v;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if ((tid & 63u) >= d) x += y;
+      }
+      if ((tid & 63u) == 63u) wave_tot[tid >> 6] = x;
+      toff[tid] = x - v;             // exclusive inside the wave
+      gpos[tid] = cur[tid];
+      cur[tid] += v;
+      hist[tid] = 0;
+    }
+    __syncthreads();
+    {
+      uint32_t add = 0;
+      for (uint32_t w = 0; w < (tid >> 6); w++) add += wave_tot[w];
+      toff[tid] += add;
+      if (tid == 255u) toff[kSortMaxBins] = add + wave_tot[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < kSortEpt; e++)
+      if (valid[e]) stage[toff[key[e] >> shift] + rank[e]] = make_uint2(payload[e], key[e]);
+    __syncthreads();
+    const uint32_t total = toff[kSortMaxBins];
+#pragma unroll
+    for (uint32_t e = 0; e < kSortEpt; e++) {
+      uint32_t s = e * 256u + tid;
+      if (s < total) {
+        uint2 v = stage[s];
+        uint32_t b = v.y >> shift;
+        uint32_t pos = gpos[b] + (s - toff[b]);
+        if (LAST) sorted[pos] = v.x;
+        else out[pos] = make_uint2(v.x, v.y & keymask);
+      }
+    }
+    __syncthreads();
   }
 }
 
