@@ -112,3 +112,36 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"oracle[/.]|liboracle|c_oracle|import oracle|from oracle", text):
                     bad.append(os.path.join(base, f))
     assert bad == []
+
+
+def test_prover_server_lifecycle_without_gpu(zk, tmp_path):
+    """Server mode of the CLI on a box without a GPU: the resident process starts, answers with the library's
+    loud "no HIP device" failure (exit 1, no outputs), and stops on request. On a GPU box the same sequence
+    is the parity test tests/test_gpu_prove.py::test_prover_cli_server_mode."""
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked server test")
+    g = golden_case("n8")
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "w.wtns").write_bytes(g["witness.wtns"])
+    sock = str(tmp_path / "p.sock")
+    env = dict(os.environ, ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="30")
+    try:
+        rc = subprocess.run([zk.PROVER_BIN, "c.zkey", "w.wtns", "proof.json", "public.json"], env=env, cwd=tmp_path,
+                            capture_output=True, text=True, timeout=120)
+        assert rc.returncode == 1 and "no HIP device" in rc.stderr
+        assert os.path.exists(sock)                                  # the server is up and answered
+        assert not (tmp_path / "proof.json").exists() and not (tmp_path / "public.json").exists()
+        rc = subprocess.run([zk.PROVER_BIN, "c.zkey", "missing.wtns", "proof.json", "public.json"], env=env,
+                            cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert rc.returncode == 1 and "cannot read witness file" in rc.stderr
+    finally:
+        rc = subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+    assert rc.returncode == 0
+    for _ in range(100):
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.05)
+    assert not os.path.exists(sock)

@@ -6,6 +6,7 @@ import os
 import random
 import struct
 import subprocess
+import time
 
 import pytest
 
@@ -161,6 +162,53 @@ def test_prover_cli_drop_in(zk, tmp_path):
     assert rc.returncode == 0, rc.stderr
     assert (tmp_path / "proof_s.json").read_text() == g["proof_snarkjs.json"]
     assert (tmp_path / "public_s.json").read_text() == g["public_snarkjs.json"]
+
+
+def test_prover_cli_server_mode(zk, tmp_path):
+    """ZKPOA_SERVER: same argv, exit codes and output bytes, but the proofs come from a resident prover
+    process that keeps the key in HBM between calls (second call = cache hit)."""
+    g, g8 = golden_case("n128"), golden_case("n8")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    (tmp_path / "short.wtns").write_bytes(g8["witness.wtns"])
+    sock = str(tmp_path / "prover.sock")
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_SERVER=sock, ZKPOA_VERBOSE="1",
+               ZKPOA_SERVER_IDLE_S="60")
+
+    def run(wtns, proof, public, **extra):
+        return subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", wtns, proof, public], env=dict(env, **extra),
+                              capture_output=True, text=True, cwd=tmp_path, timeout=120)   # relative paths on purpose
+    try:
+        rc = run("witness.wtns", "proof.json", "public.json")
+        assert rc.returncode == 0, rc.stderr
+        assert "prover server pid" in rc.stderr
+        assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+        assert (tmp_path / "public.json").read_text() == g["public_rapidsnark.json"]
+        rc = run("witness.wtns", "proof_s.json", "public_s.json", ZKPOA_JSON="snarkjs")
+        assert rc.returncode == 0, rc.stderr
+        assert (tmp_path / "proof_s.json").read_text() == g["proof_snarkjs.json"]
+        assert (tmp_path / "public_s.json").read_text() == g["public_snarkjs.json"]
+        log = (tmp_path / "prover.sock.log").read_text()
+        assert log.count("zkey load") == 1 and log.count("zkey cached") == 1      # uploaded once, reused once
+        # a failing request: rapidsnark's message, exit code 1, no output files, and the server stays up
+        rc = run("short.wtns", "bad.json", "bad_public.json")
+        assert rc.returncode == 1 and "Invalid witness length" in rc.stderr
+        assert not (tmp_path / "bad.json").exists() and not (tmp_path / "bad_public.json").exists()
+        rc = run("witness.wtns", "proof2.json", "public2.json")
+        assert rc.returncode == 0 and (tmp_path / "proof2.json").read_text() == g["proof_rapidsnark.json"]
+        # a rewritten key file is a different key (mtime / inode), never a stale hit
+        os.utime(tmp_path / "circuit_final.zkey", ns=(1, 1))
+        rc = run("witness.wtns", "proof3.json", "public3.json")
+        assert rc.returncode == 0 and (tmp_path / "proof3.json").read_text() == g["proof_rapidsnark.json"]
+        assert (tmp_path / "prover.sock.log").read_text().count("zkey load") == 2
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+    for _ in range(100):
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.05)
+    assert not os.path.exists(sock)
 
 
 def test_prover_cli_failure_leaves_no_output(zk, tmp_path):

@@ -61,3 +61,16 @@ for i in range(2):
     print("prover CLI run %d (page-cached zkey file, process start + HIP init + mmap + upload + prove + JSON): %.2f s  rc=%d  %s" % (i, tc, rc.returncode, " || ".join(rc.stderr.strip().splitlines())))
 assert open(d + "/proof.json").read() == z.proof_to_json(want)
 print("CLI proof.json matches the resident-key proof")
+
+# 3. the same CLI calls through the resident prover server (ZKPOA_SERVER): key uploaded once, then cache hits
+senv = dict(env, ZKPOA_SERVER=d + "/prover.sock", ZKPOA_SERVER_IDLE_S="60")
+try:
+    for i in range(4):
+        t0 = time.perf_counter()
+        rc = subprocess.run([z.PROVER_BIN, d + "/c.zkey", d + "/w.wtns", d + "/proof_srv.json", d + "/public_srv.json"], env=senv, capture_output=True, text=True)
+        tc = time.perf_counter() - t0
+        print("prover CLI via server, call %d (%s): %.3f s  rc=%d  %s" % (i, "server start + HIP init + key upload" if i == 0 else "key resident in HBM", tc, rc.returncode, " || ".join(rc.stderr.strip().splitlines())))
+    assert open(d + "/proof_srv.json").read() == z.proof_to_json(want)
+    print("server-mode proof.json matches the resident-key proof")
+finally:
+    subprocess.run([z.PROVER_BIN, "--stop-server"], env=senv)

@@ -661,6 +661,7 @@ int emit(const std::string& s, char* buffer, unsigned long* size) {
 
 std::mutex g_ctx_mutex;
 zkpoa_context* g_ctx = nullptr;
+std::mutex g_prove_mutex;   // one-shot entry points share the process-wide context: one proof at a time
 
 zkpoa_context* process_context(std::string& err) {
   std::lock_guard<std::mutex> lk(g_ctx_mutex);
@@ -675,6 +676,43 @@ zkpoa_context* process_context(std::string& err) {
   return g_ctx;
 }
 
+// prove with a resident key, JSON out; options from the environment (ZKPOA_R / ZKPOA_S / ZKPOA_JSON / ZKPOA_VERBOSE)
+int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+                  unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+                  unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, bool cache_hit) {
+  int rc = PROVER_OK;
+  uint8_t rb[32], sb[32];
+  const uint8_t *rp = nullptr, *sp = nullptr;
+  if (const char* e = getenv("ZKPOA_R")) {
+    if (!parse_decimal_mod_r(e, rb)) throw ProverError(PROVER_ERROR, "ZKPOA_R is not a decimal number");
+    rp = rb;
+  }
+  if (const char* e = getenv("ZKPOA_S")) {
+    if (!parse_decimal_mod_r(e, sb)) throw ProverError(PROVER_ERROR, "ZKPOA_S is not a decimal number");
+    sp = sb;
+  }
+  int style = 0;
+  if (const char* e = getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
+  uint8_t pts[256];
+  std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
+  prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
+  std::string pj = proof_json(pts, style), uj = public_json(pub.data(), zk->nPublic, style);
+  int r1 = emit(pj, proof_buffer, proof_size);
+  int r2 = emit(uj, public_buffer, public_size);
+  if (r1 != PROVER_OK || r2 != PROVER_OK) {
+    rc = PROVER_ERROR_SHORT_BUFFER;
+    set_err(error_msg, error_msg_maxsize, "output buffer too small");
+  }
+  if (getenv("ZKPOA_VERBOSE")) {
+    fprintf(stderr,
+            "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
+            "msm phase %.2f ms, prove %.2f ms\n",
+            zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, cache_hit ? "cached," : "load", load_ms,
+            load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
+  }
+  return rc;
+}
+
 int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
              unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
              unsigned long error_msg_maxsize) {
@@ -684,6 +722,7 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
     set_err(error_msg, error_msg_maxsize, err);
     return PROVER_ERROR;
   }
+  std::lock_guard<std::mutex> lk(g_prove_mutex);
   zkpoa_zkey* zk = nullptr;
   int rc = PROVER_OK;
   try {
@@ -691,35 +730,8 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
     auto tl0 = std::chrono::steady_clock::now();
     zk = zkey_load_impl(ctx, zkey, zkey_size);
     const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
-    uint8_t rb[32], sb[32];
-    const uint8_t *rp = nullptr, *sp = nullptr;
-    if (const char* e = getenv("ZKPOA_R")) {
-      if (!parse_decimal_mod_r(e, rb)) throw ProverError(PROVER_ERROR, "ZKPOA_R is not a decimal number");
-      rp = rb;
-    }
-    if (const char* e = getenv("ZKPOA_S")) {
-      if (!parse_decimal_mod_r(e, sb)) throw ProverError(PROVER_ERROR, "ZKPOA_S is not a decimal number");
-      sp = sb;
-    }
-    int style = 0;
-    if (const char* e = getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
-    uint8_t pts[256];
-    std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
-    prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
-    std::string pj = proof_json(pts, style), uj = public_json(pub.data(), zk->nPublic, style);
-    int r1 = emit(pj, proof_buffer, proof_size);
-    int r2 = emit(uj, public_buffer, public_size);
-    if (r1 != PROVER_OK || r2 != PROVER_OK) {
-      rc = PROVER_ERROR_SHORT_BUFFER;
-      set_err(error_msg, error_msg_maxsize, "output buffer too small");
-    }
-    if (getenv("ZKPOA_VERBOSE")) {
-      fprintf(stderr,
-              "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey load %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
-              "msm phase %.2f ms, prove %.2f ms\n",
-              zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, load_ms,
-              (double)zkey_size / load_ms / 1e6, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
-    }
+    rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                       error_msg_maxsize, load_ms, zkey_size, false);
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
@@ -728,6 +740,123 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
     rc = PROVER_ERROR;
   }
   if (zk) {
+    zk->release();
+    delete zk;
+  }
+  return rc;
+}
+
+// ---- device-resident key cache of groth16_prover_zkey_file ("optional device-resident zkey
+// cache keyed by path+mtime") ----------------------------------------------------------------------------
+// A long-lived caller (the prover server behind the CLI, or an FFI host process) proves many witnesses against
+// the same few keys (full_workflow.sh: layer one and two once per batch); uploading 1-21 GB and rebuilding the
+// CSR each time is most of a call. Keyed by (device, inode, size, mtime): a rewritten file is a different key.
+// ZKPOA_KEY_CACHE = number of keys kept (default 2, 0 = off); least recently used goes first, and everything
+// goes when an upload runs out of HBM.
+struct CachedKey {
+  dev_t dev;
+  ino_t ino;
+  off_t size;
+  struct timespec mtime;
+  zkpoa_zkey* zk;
+  uint64_t last_use;
+};
+std::vector<CachedKey> g_key_cache;
+uint64_t g_key_clock = 0;
+
+size_t key_cache_capacity() {
+  const char* e = getenv("ZKPOA_KEY_CACHE");
+  if (!e || !*e) return 2;
+  long v = atol(e);
+  return v < 0 ? 0 : (size_t)v;
+}
+
+void key_cache_drop(size_t idx) {
+  (void)hipDeviceSynchronize();
+  g_key_cache[idx].zk->release();
+  delete g_key_cache[idx].zk;
+  g_key_cache.erase(g_key_cache.begin() + (long)idx);
+}
+
+void key_cache_clear() {
+  while (!g_key_cache.empty()) key_cache_drop(g_key_cache.size() - 1);
+}
+
+int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+                    unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+                    unsigned long error_msg_maxsize) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) {
+    set_err(error_msg, error_msg_maxsize, std::string("cannot open zkey file ") + path);
+    return PROVER_ERROR;
+  }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size == 0) {
+    close(fd);
+    set_err(error_msg, error_msg_maxsize, std::string("cannot stat zkey file ") + path);
+    return PROVER_ERROR;
+  }
+  std::string err;
+  zkpoa_context* ctx = process_context(err);
+  if (!ctx) {
+    close(fd);
+    set_err(error_msg, error_msg_maxsize, err);
+    return PROVER_ERROR;
+  }
+  std::lock_guard<std::mutex> lk(g_prove_mutex);
+  int rc = PROVER_OK;
+  zkpoa_zkey* zk = nullptr;
+  bool owned = false, hit = false;
+  double load_ms = 0;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    const size_t cap = key_cache_capacity();
+    for (auto& c : g_key_cache)
+      if (c.dev == sb.st_dev && c.ino == sb.st_ino && c.size == sb.st_size && c.mtime.tv_sec == sb.st_mtim.tv_sec &&
+          c.mtime.tv_nsec == sb.st_mtim.tv_nsec) {
+        zk = c.zk;
+        c.last_use = ++g_key_clock;
+        hit = true;
+      }
+    if (!zk) {
+      void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (map == MAP_FAILED) throw ProverError(PROVER_ERROR, std::string("cannot mmap zkey file ") + path);
+      auto tl0 = std::chrono::steady_clock::now();
+      try {
+        while (cap && g_key_cache.size() >= cap) {   // make room first: least recently used
+          size_t lru = 0;
+          for (size_t i = 1; i < g_key_cache.size(); i++)
+            if (g_key_cache[i].last_use < g_key_cache[lru].last_use) lru = i;
+          key_cache_drop(lru);
+        }
+        try {
+          zk = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+        } catch (const HipError&) {
+          if (g_key_cache.empty()) throw;
+          key_cache_clear();                          // probably out of HBM: retry with nothing else resident
+          (void)hipGetLastError();
+          zk = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+        }
+      } catch (...) {
+        munmap(map, (size_t)sb.st_size);
+        throw;
+      }
+      munmap(map, (size_t)sb.st_size);
+      load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
+      if (cap) g_key_cache.push_back({sb.st_dev, sb.st_ino, sb.st_size, sb.st_mtim, zk, ++g_key_clock});
+      else owned = true;
+    }
+    rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                       error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
+  } catch (const ProverError& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = e.code;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR;
+  }
+  close(fd);
+  if (owned && zk) {
     zk->release();
     delete zk;
   }
@@ -1104,26 +1233,6 @@ extern "C" int groth16_prover_zkey_file(const char* zkey_file_path, const void* 
     set_err(error_msg, error_msg_maxsize, "null argument");
     return PROVER_ERROR;
   }
-  int fd = open(zkey_file_path, O_RDONLY);
-  if (fd < 0) {
-    set_err(error_msg, error_msg_maxsize, std::string("cannot open zkey file ") + zkey_file_path);
-    return PROVER_ERROR;
-  }
-  struct stat sb;
-  if (fstat(fd, &sb) != 0 || sb.st_size == 0) {
-    close(fd);
-    set_err(error_msg, error_msg_maxsize, std::string("cannot stat zkey file ") + zkey_file_path);
-    return PROVER_ERROR;
-  }
-  void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  if (map == MAP_FAILED) {
-    set_err(error_msg, error_msg_maxsize, std::string("cannot mmap zkey file ") + zkey_file_path);
-    return PROVER_ERROR;
-  }
-  int rc = one_shot(reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size,
-                    reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer, proof_size, public_buffer,
-                    public_size, error_msg, error_msg_maxsize);
-  munmap(map, (size_t)sb.st_size);
-  return rc;
+  return zkey_file_prove(zkey_file_path, reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer,
+                         proof_size, public_buffer, public_size, error_msg, error_msg_maxsize);
 }

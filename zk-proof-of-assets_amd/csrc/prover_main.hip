@@ -4,13 +4,29 @@
 // Exit status 0 on success; non-zero with a message on stderr otherwise, so the reference's
 // `set -eE` / ERR trap (scripts/lib/error_handling.sh:14-41) fires. Outputs are written to a
 // temporary name and renamed, so a failed run never leaves a partial proof.json.
+//
+// Server mode (opt-in, ZKPOA_SERVER=1 or =/path/to.sock): the reference proves layer one and layer two once
+// per batch with the SAME zkey (scripts/full_workflow.sh:497-552), and a one-shot process spends most of its
+// life on HIP start-up and on uploading 1-21 GB of key. With ZKPOA_SERVER set, `prover` keeps the same argv and
+// exit codes but hands the four paths to a resident prover process over a unix socket (started on first use,
+// one per device, exits after ZKPOA_SERVER_IDLE_S seconds without work, default 600); that process keeps the
+// keys in HBM (groth16_prover_zkey_file's cache, keyed by inode + size + mtime). `prover --stop-server` ends it.
+// The socket lives in a 0700 directory of the calling user and the server checks the peer's uid.
 #include "../../include/zkpoa_prover.h"
 
+#include <errno.h>
 #include <fcntl.h>
+#include <limits.h>
+#include <poll.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/file.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/un.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -51,35 +67,277 @@ static double now_ms() {
   return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 
-int main(int argc, char** argv) {
-  const double t_start = now_ms();
-  if (argc != 5) {
-    fprintf(stderr, "Invalid number of parameters\nUsage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>\n");
-    return EXIT_FAILURE;
-  }
+// ---- one proof in this process: (zkey path, wtns path) -> files; message = what goes to stderr ------------
+static int prove_files(const char* zkey, const char* wtns_path, const char* proof_path, const char* public_path,
+                       std::string& message) {
   std::vector<char> wtns;
-  if (!read_file(argv[2], wtns)) {
-    fprintf(stderr, "Error: cannot read witness file %s\n", argv[2]);
+  if (!read_file(wtns_path, wtns)) {
+    message = std::string("Error: cannot read witness file ") + wtns_path;
     return EXIT_FAILURE;
   }
   unsigned long proof_size = 1 << 12, public_size = 1 << 16;
   std::vector<char> proof(proof_size), pub(public_size);
   char err[1024] = {0};
-  int rc = groth16_prover_zkey_file(argv[1], wtns.data(), wtns.size(), proof.data(), &proof_size, pub.data(),
+  int rc = groth16_prover_zkey_file(zkey, wtns.data(), wtns.size(), proof.data(), &proof_size, pub.data(),
                                     &public_size, err, sizeof(err));
   if (rc == PROVER_ERROR_SHORT_BUFFER) {
     proof.resize(proof_size);
     pub.resize(public_size);
-    rc = groth16_prover_zkey_file(argv[1], wtns.data(), wtns.size(), proof.data(), &proof_size, pub.data(),
-                                  &public_size, err, sizeof(err));
+    rc = groth16_prover_zkey_file(zkey, wtns.data(), wtns.size(), proof.data(), &proof_size, pub.data(), &public_size,
+                                  err, sizeof(err));
   }
   if (rc != PROVER_OK) {
-    fprintf(stderr, "Error: %s\n", err);
+    message = std::string("Error: ") + err;
     return EXIT_FAILURE;
   }
-  if (!write_atomic(argv[3], proof.data()) || !write_atomic(argv[4], pub.data())) {
-    fprintf(stderr, "Error: cannot write %s / %s\n", argv[3], argv[4]);
+  if (!write_atomic(proof_path, proof.data()) || !write_atomic(public_path, pub.data())) {
+    message = std::string("Error: cannot write ") + proof_path + " / " + public_path;
     return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}
+
+// ---- server mode ---------------------------------------------------------------------------------------
+// Wire format, both directions: u32 length + payload. Request payload = NUL-separated fields
+//   "prove" zkey wtns proof public R S JSON VERBOSE   (absolute paths; option fields may be empty)
+//   "stop"
+// Reply payload = one status byte ('0' + exit code) followed by the message for stderr.
+static bool send_all(int fd, const void* buf, size_t len) {
+  const char* p = static_cast<const char*>(buf);
+  while (len) {
+    ssize_t n = send(fd, p, len, MSG_NOSIGNAL);
+    if (n <= 0) {
+      if (n < 0 && errno == EINTR) continue;
+      return false;
+    }
+    p += n;
+    len -= (size_t)n;
+  }
+  return true;
+}
+static bool recv_all(int fd, void* buf, size_t len) {
+  char* p = static_cast<char*>(buf);
+  while (len) {
+    ssize_t n = recv(fd, p, len, 0);
+    if (n <= 0) {
+      if (n < 0 && errno == EINTR) continue;
+      return false;
+    }
+    p += n;
+    len -= (size_t)n;
+  }
+  return true;
+}
+static bool send_msg(int fd, const std::string& m) {
+  uint32_t len = (uint32_t)m.size();
+  return send_all(fd, &len, 4) && send_all(fd, m.data(), m.size());
+}
+static bool recv_msg(int fd, std::string& m) {
+  uint32_t len = 0;
+  if (!recv_all(fd, &len, 4) || len > (1u << 20)) return false;
+  m.resize(len);
+  return len == 0 || recv_all(fd, &m[0], len);
+}
+
+static std::string server_socket_path() {
+  const char* e = getenv("ZKPOA_SERVER");
+  if (e && e[0] == '/') return e;
+  const char* dev = getenv("ZKPOA_DEVICE");
+  return "/tmp/zkpoa-" + std::to_string((long)getuid()) + "/prover-dev" + (dev && *dev ? dev : "0") + ".sock";
+}
+
+// the socket's directory must be ours alone (created 0700 if missing)
+static bool secure_dir(const std::string& sock) {
+  std::string dir = sock.substr(0, sock.rfind('/'));
+  if (dir.empty()) return false;
+  if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
+  struct stat sb;
+  if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid()) return false;
+  return (sb.st_mode & 0077) == 0 || getenv("ZKPOA_SERVER")[0] == '/';   // an explicit path is the caller's choice
+}
+
+static int connect_to(const std::string& sock) {
+  int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+  if (fd < 0) return -1;
+  struct sockaddr_un sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sun_family = AF_UNIX;
+  if (sock.size() >= sizeof(sa.sun_path)) {
+    close(fd);
+    return -1;
+  }
+  strcpy(sa.sun_path, sock.c_str());
+  if (connect(fd, reinterpret_cast<struct sockaddr*>(&sa), sizeof(sa)) != 0) {
+    close(fd);
+    return -1;
+  }
+  return fd;
+}
+
+static void set_or_clear(const char* name, const std::string& v) {
+  if (v.empty()) unsetenv(name);
+  else setenv(name, v.c_str(), 1);
+}
+
+// The resident prover: serves requests one at a time (the GPU is the shared resource) until idle or told to stop.
+static int server_main(const std::string& sock) {
+  std::string lockp = sock + ".lock";
+  int lock = open(lockp.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+  if (lock < 0 || flock(lock, LOCK_EX | LOCK_NB) != 0) return 0;   // another server owns this socket
+  unlink(sock.c_str());                                           // stale socket of a dead server
+  int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+  struct sockaddr_un sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sun_family = AF_UNIX;
+  strcpy(sa.sun_path, sock.c_str());
+  mode_t old = umask(0077);
+  bool ok = ls >= 0 && bind(ls, reinterpret_cast<struct sockaddr*>(&sa), sizeof(sa)) == 0 && listen(ls, 64) == 0;
+  umask(old);
+  if (!ok) return 1;
+  int idle_s = 600;
+  if (const char* e = getenv("ZKPOA_SERVER_IDLE_S")) idle_s = atoi(e) > 0 ? atoi(e) : idle_s;
+  bool running = true;
+  while (running) {
+    struct pollfd pfd = {ls, POLLIN, 0};
+    int pr = poll(&pfd, 1, idle_s * 1000);
+    if (pr == 0) break;          // idle: give the HBM back
+    if (pr < 0) {
+      if (errno == EINTR) continue;
+      break;
+    }
+    int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+    if (c < 0) continue;
+    struct ucred cred;
+    socklen_t cl = sizeof(cred);
+    std::string req, reply;
+    if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cred, &cl) != 0 || cred.uid != getuid()) {
+      close(c);
+      continue;
+    }
+    if (recv_msg(c, req)) {
+      std::vector<std::string> f;
+      size_t pos = 0;
+      while (pos <= req.size()) {
+        size_t e = req.find('\0', pos);
+        if (e == std::string::npos) e = req.size();
+        f.push_back(req.substr(pos, e - pos));
+        pos = e + 1;
+      }
+      if (!f.empty() && f[0] == "stop") {
+        reply = "0";
+        running = false;
+      } else if (f.size() >= 9 && f[0] == "prove") {
+        set_or_clear("ZKPOA_R", f[5]);
+        set_or_clear("ZKPOA_S", f[6]);
+        set_or_clear("ZKPOA_JSON", f[7]);
+        set_or_clear("ZKPOA_VERBOSE", f[8]);   // the library's phase line goes to <socket>.log
+        const double t0 = now_ms();
+        std::string message;
+        int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message);
+        if (rc == EXIT_SUCCESS && !f[8].empty())
+          message = "zkpoa: prover server pid " + std::to_string((long)getpid()) + " served the proof in " +
+                    std::to_string(now_ms() - t0) + " ms";
+        reply = std::string(1, (char)('0' + rc)) + message;
+      } else {
+        reply = "1Error: malformed request to the prover server";
+      }
+      send_msg(c, reply);
+    }
+    close(c);
+  }
+  close(ls);
+  unlink(sock.c_str());
+  close(lock);
+  return 0;
+}
+
+static std::string abs_path(const char* p) {
+  if (p[0] == '/') return p;
+  char cwd[PATH_MAX];
+  if (!getcwd(cwd, sizeof(cwd))) return p;
+  return std::string(cwd) + "/" + p;
+}
+
+// Client side. Returns the exit code, or -1 when no server could be reached (the caller proves in-process).
+static int client_main(char** argv, const std::string& sock, bool stop) {
+  int fd = connect_to(sock);
+  if (fd < 0 && stop) return EXIT_SUCCESS;   // nothing to stop
+  if (fd < 0) {
+    if (!secure_dir(sock)) {
+      fprintf(stderr, "zkpoa: server socket directory of %s is not private to this user; proving in-process\n",
+              sock.c_str());
+      return -1;
+    }
+    // start the server: a detached child of this (GPU-free) process
+    pid_t pid = fork();
+    if (pid == 0) {
+      setsid();
+      pid_t p2 = fork();
+      if (p2 != 0) _exit(0);
+      int devnull = open("/dev/null", O_RDWR);
+      std::string logp = sock + ".log";
+      int log = open(logp.c_str(), O_CREAT | O_WRONLY | O_APPEND, 0600);
+      dup2(devnull, 0);
+      dup2(log >= 0 ? log : devnull, 1);
+      dup2(log >= 0 ? log : devnull, 2);
+      (void)chdir("/");
+      _exit(server_main(sock));
+    }
+    if (pid > 0) (void)waitpid(pid, nullptr, 0);   // the intermediate child exits at once
+    for (int i = 0; i < 200 && fd < 0; i++) {   // the server listens before it touches the GPU: normally a few ms
+      usleep(i < 20 ? 5000 : 50000);
+      fd = connect_to(sock);
+    }
+    if (fd < 0) return -1;
+  }
+  std::string req;
+  if (stop) {
+    req = "stop";
+  } else {
+    auto env = [](const char* n) { const char* e = getenv(n); return std::string(e ? e : ""); };
+    const std::string fields[] = {"prove", abs_path(argv[1]), abs_path(argv[2]), abs_path(argv[3]), abs_path(argv[4]),
+                                  env("ZKPOA_R"), env("ZKPOA_S"), env("ZKPOA_JSON"), env("ZKPOA_VERBOSE")};
+    for (size_t i = 0; i < 9; i++) {
+      if (i) req.push_back('\0');
+      req += fields[i];
+    }
+  }
+  std::string reply;
+  if (!send_msg(fd, req) || !recv_msg(fd, reply) || reply.empty()) {
+    close(fd);
+    fprintf(stderr, "Error: the prover server closed the connection\n");
+    return EXIT_FAILURE;
+  }
+  close(fd);
+  if (reply.size() > 1) fprintf(stderr, "%s\n", reply.c_str() + 1);
+  return reply[0] - '0';
+}
+
+int main(int argc, char** argv) {
+  const double t_start = now_ms();
+  const char* srv = getenv("ZKPOA_SERVER");
+  const bool use_server = srv && *srv && strcmp(srv, "0") != 0;
+  if (argc == 2 && strcmp(argv[1], "--stop-server") == 0) {
+    if (!use_server) setenv("ZKPOA_SERVER", "1", 1);
+    return client_main(argv, server_socket_path(), true);
+  }
+  if (argc != 5) {
+    fprintf(stderr, "Invalid number of parameters\nUsage: prover <circuit.zkey> <witness.wtns> <proof.json> <public.json>\n");
+    return EXIT_FAILURE;
+  }
+  if (use_server) {
+    int rc = client_main(argv, server_socket_path(), false);
+    if (rc >= 0) {
+      if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: prover process total %.1f ms\n", now_ms() - t_start);
+      return rc;
+    }
+    // no server reachable: prove in this process (still on the GPU)
+  }
+  std::string message;
+  int rc = prove_files(argv[1], argv[2], argv[3], argv[4], message);
+  if (rc != EXIT_SUCCESS) {
+    fprintf(stderr, "%s\n", message.c_str());
+    return rc;
   }
   if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: prover process total %.1f ms\n", now_ms() - t_start);
   // Both outputs are complete and renamed into place: leave without running the HIP runtime's teardown
