@@ -6,6 +6,14 @@ DST = os.path.join(ROOT, "profiles")
 for old in glob.glob(os.path.join(DST, "r01_*")):
     os.remove(old)
 
+def only(pattern):
+    """exactly one match: gpurun merges into an existing gpurun_out/, so stale runs must be deleted first"""
+    fs = glob.glob(pattern)
+    if len(fs) != 1:
+        sys.exit("expected one file for %s, found %d: rm -rf gpurun_out/profiles_r01 and collect again" % (pattern, len(fs)))
+    return fs[0]
+
+
 def last_json_line(path):
     for line in reversed(open(path).read().splitlines()):
         if line.startswith("{"):
@@ -17,12 +25,11 @@ for f in glob.glob(os.path.join(SRC, "bench_*.json.log")):
     if line:
         open(os.path.join(DST, "r01_" + os.path.basename(f)), "w").write(line + "\n")
 for tag in ("default", "inflight1", "msm26", "prove25"):
-    fs = glob.glob(os.path.join(SRC, "stats_" + tag, "*", "*kernel_stats.csv"))
-    if fs:
-        shutil.copy(fs[0], os.path.join(DST, "r01_kernel_stats_%s.csv" % tag))
+    shutil.copy(only(os.path.join(SRC, "stats_" + tag, "*", "*kernel_stats.csv")),
+                os.path.join(DST, "r01_kernel_stats_%s.csv" % tag))
 
 def summarize(tag, counter):
-    f = glob.glob(os.path.join(SRC, "pmc_%s_%s" % (tag, counter), "*", "*counter_collection.csv"))[0]
+    f = only(os.path.join(SRC, "pmc_%s_%s" % (tag, counter), "*", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -46,8 +53,14 @@ for tag, name in (("msm20", "msm_g1_2p20"), ("msm26", "msm_g1_2p26")):
     for kk in f:
         if "zkpoa::" in kk and "gen_bases" not in kk and "to_affine" not in kk:
             short = kk.split("(")[0].replace("void ", "")
-            ks[short] = {"dispatches": f[kk][0], "FETCH_SIZE_KiB": f[kk][1], "WRITE_SIZE_KiB": w.get(kk, (0, 0))[1],
-                         "bytes_per_launch": (f[kk][1] + w.get(kk, (0, 0))[1]) * 1024}
+            # MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of a wide coalesced streaming read on gfx950
+            # (128-B requests tallied at 64 B) -> doubled for the streaming kernels; the 64-B gathers of the
+            # accumulation kernel read true bytes (calibration above) -> factor 1; WRITE_SIZE is exact.
+            streaming = any(t in short for t in ("digits", "sort_", "scan_", "piece_"))
+            fc = 2.0 if streaming else 1.0
+            ks[short] = {"dispatches": f[kk][0], "FETCH_SIZE_KiB": f[kk][1], "fetch_correction": fc,
+                         "WRITE_SIZE_KiB": w.get(kk, (0, 0))[1],
+                         "bytes_per_launch": (fc * f[kk][1] + w.get(kk, (0, 0))[1]) * 1024}
     out["workloads"][name] = ks
 json.dump(out, open(os.path.join(DST, "r01_pmc_hbm_traffic.json"), "w"), indent=1)
 for extra in ("pcie_inclusive2.log",):
