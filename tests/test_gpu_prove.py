@@ -197,6 +197,13 @@ def test_prover_cli_server_mode(zk, tmp_path):
         assert not (tmp_path / "bad.json").exists() and not (tmp_path / "bad_public.json").exists()
         rc = run("witness.wtns", "proof2.json", "public2.json")
         assert rc.returncode == 0 and (tmp_path / "proof2.json").read_text() == g["proof_rapidsnark.json"]
+        # several prover processes at once (one per GNU-parallel batch, full_workflow.sh:552): served one at a time
+        procs = [subprocess.Popen([zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "par%d.json" % i, "parpub%d.json" % i],
+                                  env=env, cwd=tmp_path, stderr=subprocess.PIPE, text=True) for i in range(4)]
+        for i, pr in enumerate(procs):
+            _, err = pr.communicate(timeout=120)
+            assert pr.returncode == 0, err
+            assert (tmp_path / ("par%d.json" % i)).read_text() == g["proof_rapidsnark.json"]
         # a rewritten key file is a different key (mtime / inode), never a stale hit
         os.utime(tmp_path / "circuit_final.zkey", ns=(1, 1))
         rc = run("witness.wtns", "proof3.json", "public3.json")

@@ -669,9 +669,13 @@ zkpoa_context* process_context(std::string& err) {
   int dev = 0;
   if (const char* e = getenv("ZKPOA_DEVICE")) dev = atoi(e);
   char msg[512] = {0};
+  auto t0 = std::chrono::steady_clock::now();
   if (zkpoa_context_create(dev, &g_ctx, msg, sizeof(msg)) != PROVER_OK) {
     err = msg;
     g_ctx = nullptr;
+  } else if (getenv("ZKPOA_VERBOSE")) {
+    fprintf(stderr, "zkpoa: HIP runtime + context ready in %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   return g_ctx;
 }
