@@ -111,10 +111,12 @@ def test_msm_repeated_and_opposite_bases(ctx):
     assert g16.g1_from_bytes(ctx.msm_g1(bases, sc2, n)) == bn.g1_mul(bn.G1_GEN, 4 * (n // 2))
 
 
-@pytest.mark.parametrize("c", [4, 8, 11, 14, 20])
+# window widths on both sides of every sort-pass boundary (c - 1 key bits: 1 pass up to 8, 2 up to 16, 3 up to 21)
+# and of the odd / even splits of the bucket matrix in the reduction
+@pytest.mark.parametrize("c", [4, 5, 8, 9, 10, 11, 14, 16, 17, 18, 20, 22])
 def test_msm_forced_windows(ctx, c):
     rng = random.Random(c)
-    n = 4096
+    n = 4096 if c < 16 else 40000
     bases = co.fixed_base_g1(b"".join(le(rng.randrange(R)) for _ in range(n)), 8)
     sc = _rand_scalars(rng, n, "witness")
     ctx.set_option("msm_c", c)
