@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+VALU_PEAK_GADDS = 12.1      # XYZZ mixed additions/s: register-only loop of the same addition on one MI355X at its best
+                            # occupancy (tools/microbench.hip: 11.6 at 3 waves/SIMD, 12.1 at 4)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
 
@@ -293,6 +295,13 @@ def main():
         pts_total = n_local * world * args.steps
         k_ms = kernel_ms / args.steps
         achieved = G1_MSM_BYTES_PER_POINT * n_local / (k_ms * 1e-3) / 1e9
+        # the bound that actually binds: one XYZZ mixed addition per (point, window) entry; window width from the
+        # library's cost model (csrc/msm.hip.h msm_make_plan), ceiling = register-only loop of the same addition
+        # measured on this chip (tools/microbench2.hip)
+        c_win = int(os.environ.get("ZKPOA_MSM_C") or
+                    min(range(4, 23), key=lambda c: ((254 + c - 1) // c) * (n_local + 8.0 * (1 << (c - 1)))))
+        adds = n_local * ((254 + c_win - 1) // c_win)
+        gadds = adds / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "G1-MSM throughput", "value": pts_total / elapsed, "unit": "pts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,6 +320,10 @@ def main():
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                            "WRITE_SIZE, bytes per launch; each base is re-read once per window)",
                          "kernel_ms": k_ms, "msm_device_ms": msm_dev_ms / args.steps,
+                         "valu": {"unit": "G mixed additions/s", "achieved": gadds, "peak": VALU_PEAK_GADDS,
+                                  "frac": gadds / VALU_PEAK_GADDS, "additions_per_launch": adds, "window_bits": c_win,
+                                  "note": "kernel_ms is per launch with %d MSMs in flight, so launches overlap "
+                                          "other kernels; --inflight 1 gives the kernel alone" % inflight},
                          "note": "algorithmic bytes = 96 B/point x points per launch; the kernel is "
                                  "integer-VALU-bound (v_mad_u64_u32), not HBM-bound: see DESIGN.md"},
         }
