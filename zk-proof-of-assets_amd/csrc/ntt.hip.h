@@ -28,6 +28,9 @@ namespace zkpoa {
 constexpr uint32_t kNttTileLog = 11;  // 2048 elements = 64 KiB of LDS per workgroup
 constexpr uint32_t kNttStridedB = 8;  // rows per tile in strided passes (x 8 columns)
 constexpr uint32_t kNttMaxStridedB = 10;  // a single strided pass may take up to 10 stages (x 2 columns)
+// threads per 2048-element tile: 8 waves share the 64 KiB tile, so with 2 tiles per CU every SIMD has 4 waves
+// to cover the multiply latency and the per-stage barriers (measured at 2^26: 256 threads +10 %, 1024 +10 %)
+constexpr uint32_t kNttThreads = 512;
 
 // T[i] = scale * base^(i * step) for i < count  (all Montgomery)
 static __global__ __launch_bounds__(256) void fr_pow_table_kernel(Fr base, Fr scale, uint32_t count, void* out) {
@@ -65,7 +68,7 @@ ZK_DEV void lds_store(uint4* lds, uint32_t idx, const Fr& v) {
 // One pass over stages [s_lo, s_lo + B). Tile: 2^B rows (stride 2^s_lo elements) x 2^logT columns
 // (consecutive elements); requires logT <= s_lo. grid.x = n / 2^(B+logT).
 template <bool DIF>
-static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__ data, uint32_t k, uint32_t s_lo,
+static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(void* __restrict__ data, uint32_t k, uint32_t s_lo,
                                                               uint32_t B, uint32_t logT,
                                                               const void* __restrict__ small_tw,
                                                               const void* __restrict__ tw_hi,
@@ -79,7 +82,7 @@ static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__
   const uint32_t shift = k - (s_lo + B);  // log2(n / N')
   char* d = reinterpret_cast<char*>(data);
 
-  for (uint32_t e = tid; e < tile; e += 256u) {
+  for (uint32_t e = tid; e < tile; e += kNttThreads) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
     Fr v = load_field<Fr>(d + 32 * p);
@@ -95,7 +98,7 @@ static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__
   for (uint32_t it = 0; it < B; it++) {
     const uint32_t sl = DIF ? (B - 1u - it) : it;
     const uint32_t half = 1u << sl;
-    for (uint32_t b = tid; b < (tile >> 1); b += 256u) {
+    for (uint32_t b = tid; b < (tile >> 1); b += kNttThreads) {
       uint32_t c = b & (T - 1u), mb = b >> logT;
       uint32_t j = mb & (half - 1u);
       uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
@@ -119,7 +122,7 @@ static __global__ __launch_bounds__(256) void ntt_pass_kernel(void* __restrict__
     __syncthreads();
   }
 
-  for (uint32_t e = tid; e < tile; e += 256u) {
+  for (uint32_t e = tid; e < tile; e += kNttThreads) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
     Fr v = lds_load(lds, e);
@@ -339,7 +342,7 @@ struct NttEngine {
       uint32_t tile_log = ps.B + ps.logT;
       uint32_t grid = 1u << (k - tile_log);
       size_t lds_bytes = (size_t)32 << tile_log;
-      hipLaunchKernelGGL((ntt_pass_kernel<DIF>), dim3(grid), dim3(256), lds_bytes, st, d_data, k, ps.s_lo, ps.B,
+      hipLaunchKernelGGL((ntt_pass_kernel<DIF>), dim3(grid), dim3(kNttThreads), lds_bytes, st, d_data, k, ps.s_lo, ps.B,
                          ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi, (const void*)t.lo, t.L);
     }
   }
