@@ -113,12 +113,16 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
     sync()
     t0 = time.perf_counter()
     acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
+    names = ("H", "A", "B1", "B2", "C")
+    acc.update({"msm_%s" % x: 0.0 for x in names})
     for i in range(args.steps):
         pts = one_proof()
         acc["h_chain"] += ctx.last_ms(3)
         acc["msm_phase"] += ctx.last_ms(4)
         acc["prove"] += ctx.last_ms(5)
         acc["h_msm_accum"] += ctx.last_ms(1)
+        for lane, x in enumerate(names):                 # device time of each MSM on its own lane (they overlap)
+            acc["msm_%s" % x] += ctx.last_ms_lane(lane, 0)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -118,4 +118,56 @@ static __global__ __launch_bounds__(256) void strided_copy64_kernel(const uint4*
   dst[q] = src[((uint64_t)off + (uint64_t)stride * i) * 4u + (q & 3u)];
 }
 
+// ---- A / B queries without their points at infinity -----------------------------------------------------
+// zkey sections 5 and 6 / 7 hold A_i(tau)*G resp. B_i(tau)*G for EVERY wire, and a wire that never appears in
+// that matrix is the point at infinity (all-zero bytes). Those (point, scalar) pairs contribute nothing to
+// pi_a / pi_b, yet a lane that meets one still spends a whole mixed addition's time, so the key keeps compacted
+// copies of the sections plus the wire index of every kept point, and the MSMs run over gathered scalars.
+// keep[i] = 1 unless g1[i] (64 B) and, if given, g2[i] (128 B) are all-zero
+static __global__ __launch_bounds__(256) void query_keep_kernel(const uint4* __restrict__ g1, const uint4* __restrict__ g2,
+                                                                uint32_t n, uint32_t* __restrict__ keep) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint4 v = g1[(size_t)i * 4 + k];
+    o |= v.x | v.y | v.z | v.w;
+  }
+  if (g2) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint4 v = g2[(size_t)i * 8 + k];
+      o |= v.x | v.y | v.z | v.w;
+    }
+  }
+  keep[i] = o ? 1u : 0u;
+}
+
+// pos = exclusive scan of keep: kept point i goes to slot pos[i]; wire[slot] = wire0 + i
+static __global__ __launch_bounds__(256) void query_compact_kernel(const uint4* __restrict__ g1, const uint4* __restrict__ g2,
+                                                                   const uint32_t* __restrict__ pos, uint32_t n,
+                                                                   uint32_t wire0, uint4* __restrict__ c1,
+                                                                   uint4* __restrict__ c2, uint32_t* __restrict__ wire) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = pos[i];
+  if (pos[i + 1] == s) return;
+#pragma unroll
+  for (int k = 0; k < 4; k++) c1[(size_t)s * 4 + k] = g1[(size_t)i * 4 + k];
+  if (g2) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) c2[(size_t)s * 8 + k] = g2[(size_t)i * 8 + k];
+  }
+  wire[s] = wire0 + i;
+}
+
+// out[j] = values[idx[j]], 32-byte elements (two 16-byte quarters per thread pair)
+static __global__ __launch_bounds__(256) void gather32_kernel(const uint4* __restrict__ values, const uint32_t* __restrict__ idx,
+                                                              uint64_t count, uint4* __restrict__ out) {
+  uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (q >= count * 2u) return;
+  out[q] = values[(uint64_t)idx[q >> 1] * 2u + (q & 1u)];
+}
+
 }  // namespace zkpoa

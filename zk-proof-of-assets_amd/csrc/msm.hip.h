@@ -64,9 +64,13 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
   p.TB = p.W * p.Nb;
   p.logS = (uint32_t)(p.c - 1 + 1) / 2;
   p.logRows = (uint32_t)(p.c - 1) - p.logS;
-  double avg = (double)n / (double)p.Nb;
+  // Level-0 piece length. One thread adds one piece sequentially, so the accumulation kernel cannot finish
+  // before K0 dependent mixed additions have run (a G2 addition is ~15 us for a lone wave: 256 of them are
+  // 4 ms), and it needs several pieces per lane to balance. K0 ~ entries / (4 x lanes of the chip at the
+  // kernel's occupancy), within [32, 256]; buckets longer than K0 continue in the partial-sum levels.
+  const double lanes = 256.0 * 4 * 3 * 64;
   uint32_t k0 = 32;
-  while (k0 < 2 * avg && k0 < 512) k0 <<= 1;
+  while ((double)k0 < (double)n * p.W / (4.0 * lanes) && k0 < 256) k0 <<= 1;
   p.K0 = k0;
   return p;
 }

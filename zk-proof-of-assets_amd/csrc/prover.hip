@@ -122,6 +122,23 @@ struct zkpoa_zkey {
   void* dHs = nullptr;           // cyclic H shard (owned), domain / split_world points
   mutable bool h_ready = false;  // d_abc[0 .. domain/split_world) holds this proof's H scalars (stage 3 done)
   uint64_t nCoefsLocal = 0;
+  // A and B queries without their points at infinity (abc.hip.h): compacted copies of the resident range of
+  // section 5 resp. 6 / 7, the wire of every kept point, pos[i] = kept points before resident wire i (a shard's
+  // slice of the compacted arrays is [pos[wlo - wbase], pos[wlo + wcnt - wbase])), and the gathered scalars.
+  struct CompactQuery {
+    void *g1 = nullptr, *g2 = nullptr, *scalars = nullptr;
+    uint32_t *wire = nullptr, *pos = nullptr;
+    uint64_t res = 0;          // kept points in the resident range
+    uint64_t lo = 0, cnt = 0;  // this shard's slice of them
+    void release() {
+      void* ptrs[] = {g1, g2, scalars, wire, pos};
+      for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+      g1 = g2 = scalars = nullptr;
+      wire = pos = nullptr;
+    }
+  };
+  CompactQuery qA, qB;
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
   }
@@ -143,6 +160,8 @@ struct zkpoa_zkey {
     void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    qA.release();
+    qB.release();
     dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = nullptr;
     d_row_ptr = d_sig = nullptr;
   }
@@ -208,6 +227,66 @@ void set_split(zkpoa_zkey* zk, uint64_t rank, uint64_t world) {
   zk->split_rank = (uint32_t)rank;
   zk->split_log = world == 2 ? 1 : (world == 4 ? 2 : 3);
   zk->h_ready = false;
+}
+
+// this shard's slice of a compacted query: two 4-byte reads of the position array
+void query_set_slice(const zkpoa_zkey* zk, zkpoa_zkey::CompactQuery& q) {
+  uint32_t a = 0, b = 0;
+  ZK_HIP(hipMemcpy(&a, q.pos + (zk->wlo - zk->wbase), 4, hipMemcpyDeviceToHost));
+  ZK_HIP(hipMemcpy(&b, q.pos + (zk->wlo - zk->wbase + zk->wcnt), 4, hipMemcpyDeviceToHost));
+  q.lo = a;
+  q.cnt = b - a;
+}
+void queries_set_slice(zkpoa_zkey* zk) {
+  query_set_slice(zk, zk->qA);
+  query_set_slice(zk, zk->qB);
+}
+
+// Compact the resident range [wbase, wbase + wres) of a query (d1: G1 section, d2: its G2 twin or null) once per key.
+void query_compact(zkpoa_context* ctx, zkpoa_zkey* zk, zkpoa_zkey::CompactQuery& q, const void* d1, const void* d2,
+                   uint64_t wres) {
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  const uint32_t n = (uint32_t)wres;
+  DevBuf keep(((size_t)n + 1) * 4), bs(((size_t)n / kScanTile + 2) * 4), misc(64);
+  ZK_HIP(hipMalloc(reinterpret_cast<void**>(&q.pos), ((size_t)n + 1) * 4));
+  ZK_HIP(hipMemsetAsync(misc.p, 0, 64, st));
+  uint32_t total = 0;
+  if (n) {
+    hipLaunchKernelGGL(query_keep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)d1, (const uint4*)d2, n,
+                       (uint32_t*)keep.p);
+    scan_u32(st, (const uint32_t*)keep.p, n, 0, 0, q.pos, (uint32_t*)bs.p, (uint32_t*)misc.p, nullptr);
+    ZK_HIP(hipMemcpyAsync(&total, q.pos + n, 4, hipMemcpyDeviceToHost, st));
+  } else {
+    ZK_HIP(hipMemsetAsync(q.pos, 0, 4, st));
+  }
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+  q.res = total;
+  const size_t cnt = total ? total : 1;
+  ZK_HIP(hipMalloc(&q.g1, cnt * 64));
+  if (d2) ZK_HIP(hipMalloc(&q.g2, cnt * 128));
+  ZK_HIP(hipMalloc(&q.scalars, cnt * 32));
+  ZK_HIP(hipMalloc(reinterpret_cast<void**>(&q.wire), cnt * 4));
+  if (n) {
+    hipLaunchKernelGGL(query_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)d1, (const uint4*)d2,
+                       (const uint32_t*)q.pos, n, (uint32_t)zk->wbase, (uint4*)q.g1, (uint4*)q.g2, q.wire);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+  }
+  query_set_slice(zk, q);
+}
+
+// Both witness queries; when the handle owns the sections the originals are freed afterwards (nothing reads
+// them again: the MSMs use the compacted copies).
+void queries_compact(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t wres) {
+  query_compact(ctx, zk, zk->qA, zk->dA, nullptr, wres);
+  query_compact(ctx, zk, zk->qB, zk->dB1, zk->dB2, wres);
+  if (zk->owns_points) {
+    (void)hipFree(zk->dA);
+    (void)hipFree(zk->dB1);
+    (void)hipFree(zk->dB2);
+    zk->dA = zk->dB1 = zk->dB2 = nullptr;
+  }
 }
 
 zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
@@ -287,6 +366,7 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     } else {
       zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
     }
+    queries_compact(ctx, zk.get(), zk->wcnt);
     hipStream_t st = ctx->dev.lanes[0].stream;
     void* d_recs = dev_upload(ctx, s4.p + 4, zk->nCoefs * 44);
     try {
@@ -421,16 +501,16 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   std::exception_ptr errs[4];
   float msm_ms[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   const char* wit = reinterpret_cast<const char*>(zk->d_witness);
-  const char* pA = reinterpret_cast<const char*>(zk->dA) + (zk->wlo - zk->wbase) * 64;
-  const char* pB1 = reinterpret_cast<const char*>(zk->dB1) + (zk->wlo - zk->wbase) * 64;
-  const char* pB2 = reinterpret_cast<const char*>(zk->dB2) + (zk->wlo - zk->wbase) * 128;
+  // A, B1 and B2 run over the compacted queries (points at infinity dropped at key load) and gathered scalars
+  const char* pA = reinterpret_cast<const char*>(zk->qA.g1) + zk->qA.lo * 64;
+  const char* pB1 = reinterpret_cast<const char*>(zk->qB.g1) + zk->qB.lo * 64;
+  const char* pB2 = reinterpret_cast<const char*>(zk->qB.g2) + zk->qB.lo * 128;
   const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
   const bool split = zk->split_world > 1;
   if (split && !zk->h_ready)
     throw ProverError(PROVER_ERROR, "split chain: run zkpoa_split_stage1/2/3 for this witness before zkpoa_prove_partials");
   const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
                          : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
-  const char* witW = wit + zk->wlo * 32;
   const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
   auto guarded = [&](int slot, std::function<void()> fn) {
     return std::thread([&, slot, fn] {
@@ -442,23 +522,33 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       }
     });
   };
-  // Witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back). A, B1 and B2 use
-  // the same scalars (the shard's witness range), so their bucket sort runs once (lane 1) and the three
-  // accumulations read it; C (different range) sorts on its own.
+  // Witness MSMs on their own lanes (host threads: each MSM has one mid-way read-back). B1 and B2 use the
+  // same scalars (the witness values of the wires that occur in the B matrix), so their bucket sort runs once
+  // (lane 2) and both accumulations read it; A and C sort on their own lanes.
   std::promise<const MsmSorted*> sorted_promise;
   std::shared_future<const MsmSorted*> sorted_ready = sorted_promise.get_future().share();
+  auto gather = [&](int lane_id, const zkpoa_zkey::CompactQuery& q) {
+    if (q.cnt)
+      hipLaunchKernelGGL(gather32_kernel, dim3((uint32_t)((q.cnt * 2 + 255) / 256)), dim3(256), 0,
+                         ctx->dev.lanes[lane_id].stream, (const uint4*)zk->d_witness, (const uint32_t*)q.wire + q.lo,
+                         q.cnt, (uint4*)q.scalars);
+  };
   std::thread tA = guarded(0, [&] {
+    gather(1, zk->qA);
+    msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1]);
+  });
+  std::thread tB1 = guarded(1, [&] {
     MsmSorted* sr = nullptr;
     try {
-      sr = msm_sort_run(ctx, 1, witW, zk->wcnt);
+      gather(2, zk->qB);
+      sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt);
       sorted_promise.set_value(sr);
     } catch (...) {
       sorted_promise.set_exception(std::current_exception());
       throw;
     }
-    msm_accum_g1(ctx, 1, sr, true, pA, outA, msm_ms[1]);
+    msm_accum_g1(ctx, 2, sr, true, pB1, outB1, msm_ms[2]);
   });
-  std::thread tB1 = guarded(1, [&] { msm_accum_g1(ctx, 2, sorted_ready.get(), false, pB1, outB1, msm_ms[2]); });
   std::thread tB2 = guarded(2, [&] { msm_accum_g2(ctx, 3, sorted_ready.get(), false, pB2, outB2, msm_ms[3]); });
   std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
 
@@ -494,6 +584,10 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   ctx->ms[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();
   ctx->ms[0] = msm_ms[0][0];
   ctx->ms[1] = msm_ms[0][1];
+  for (int l = 0; l < 5; l++) {   // per-lane MSM timings (H, A, B1, B2, C): zkpoa_last_ms_lane
+    ctx->lane_ms[l][0] = msm_ms[l][0];
+    ctx->lane_ms[l][1] = msm_ms[l][1];
+  }
 }
 
 // header: alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128); sums: A B1 B2 C H summed over all shards.
@@ -910,6 +1004,11 @@ extern "C" int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t wo
   zkey->set_shard(rank, world);
   zkey->split_world = zkey->split_rank = zkey->split_log = 0;
   zkey->h_ready = false;
+  try {
+    queries_set_slice(zkey);
+  } catch (const std::exception&) {
+    return PROVER_ERROR;
+  }
   return PROVER_OK;
 }
 
@@ -942,6 +1041,7 @@ extern "C" int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, 
     hipLaunchKernelGGL(strided_copy64_kernel, dim3((uint32_t)((cnt * 4 + 255) / 256)), dim3(256), 0, st,
                        (const uint4*)zkey->dH, (uint4*)zkey->dHs, cnt, (uint32_t)rank, (uint32_t)world);
     zkey->set_shard(rank, world);
+    queries_set_slice(zkey);
     set_split(zkey, rank, world);
     ntt_prepare(ctx, st, zkey->power - zkey->split_log);
     ZK_HIP(hipStreamSynchronize(st));
@@ -1123,6 +1223,7 @@ extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint6
     zk->delta1 = h_affine_from_bytes<HFq>(header_points + 256);
     zk->delta2 = h_affine_from_bytes<HFq2>(header_points + 320);
     zk->set_full();
+    queries_compact(ctx, zk.get(), zk->nVars);
     build_csr(ctx, zk.get(), d_coef_records);
     ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power);
     ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));

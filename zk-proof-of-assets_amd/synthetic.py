@@ -11,6 +11,9 @@ nPublic+1 public rows -- with every base point a KNOWN multiple of the generator
 so the expected proof is a discrete-log computation in Fr (O(n) integer work, no CPU MSM):
     a = sum w_i A_i + al + r de,  b = sum w_i B_i + be + s de,
     c = sum w_i C_i + sum P_j H_j + s a + r b - r s de;     proof = (a*G1, b*G2, c*G1).
+As in a real zkey, a wire that does not occur in a matrix has the point at infinity (all-zero bytes) in that
+matrix's query: sections 5 (A) and 6 / 7 (B) are zeroed for the wires the random R1CS never uses there, and
+the expectation sums only over the wires that are present.
 Such a key is not a valid trusted setup (proofs do not verify); it exercises exactly the same
 kernels on the same data volumes, which is what the timing configs need, and every group element of
 the output is still checked exactly.
@@ -104,6 +107,17 @@ class SyntheticCircuit:
         pub[:, 0] = 0
         pub[:, 1] = torch.arange(n_cons, n_cons + n_public + 1, dtype=torch.int32)
         pub[:, 2] = torch.arange(0, n_public + 1, dtype=torch.int32)
+        # wires present in A (both A-terms and the public rows) and in B: the others get the point at infinity
+        in_a = torch.zeros(m, dtype=torch.bool)
+        in_b = torch.zeros(m, dtype=torch.bool)
+        in_a[sig[:, 0].long()] = True
+        in_a[sig[:, 1].long()] = True
+        in_a[:n_public + 1] = True
+        in_b[sig[:, 2].long()] = True
+        self.in_a, self.in_b = in_a.numpy(), in_b.numpy()
+        self.d_A.view(m, 64)[(~in_a).to(dev)] = 0
+        self.d_B1.view(m, 64)[(~in_b).to(dev)] = 0
+        self.d_B2.view(m, 128)[(~in_b).to(dev)] = 0
         self.n_coef = n_coef
         self.recs_host = recs                              # [n_coef, 11] int32 == 44-byte records
         self.d_recs = recs.to(dev)
@@ -141,8 +155,12 @@ class SyntheticCircuit:
     def expected_dlogs(self, r, s, h_scalars_bytes=None):
         """(a, b, c) with c = None when the H scalars are not supplied."""
         import numpy as np
-        s0, s1 = dlog_sums(self.w_limbs)
-        sums = {x: (self.par[x][0] * s0 + self.par[x][1] * s1) % R_MOD for x in ("A", "B")}
+        sums = {}
+        for x, present in (("A", self.in_a), ("B", self.in_b)):
+            limbs = self.w_limbs.copy()
+            limbs[~present] = 0                             # absent wire: point at infinity in that query
+            s0, s1 = dlog_sums(limbs)
+            sums[x] = (self.par[x][0] * s0 + self.par[x][1] * s1) % R_MOD
         de = self.hdr["delta"]
         a = (sums["A"] + self.hdr["alpha"] + r * de) % R_MOD
         b = (sums["B"] + self.hdr["beta"] + s * de) % R_MOD
