@@ -43,7 +43,7 @@ struct MsmPlan {
   uint32_t logS = 0, logRows = 0;
 };
 
-inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
+inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false) {
   MsmPlan p;
   p.n = (uint32_t)n;
   int best_c = 4;
@@ -64,13 +64,15 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0) {
   p.TB = p.W * p.Nb;
   p.logS = (uint32_t)(p.c - 1 + 1) / 2;
   p.logRows = (uint32_t)(p.c - 1) - p.logS;
-  // Level-0 piece length. One thread adds one piece sequentially, so the accumulation kernel cannot finish
-  // before K0 dependent mixed additions have run (a G2 addition is ~15 us for a lone wave: 256 of them are
-  // 4 ms), and it needs several pieces per lane to balance. K0 ~ entries / (4 x lanes of the chip at the
-  // kernel's occupancy), within [32, 256]; buckets longer than K0 continue in the partial-sum levels.
-  const double lanes = 256.0 * 4 * 3 * 64;
+  // Level-0 piece length. One thread adds one piece sequentially: about twice the mean bucket occupancy, so
+  // most buckets are a single piece (uniform scalars: 128 at 2^20, 256 at 2^26). The kernel cannot end before
+  // K0 dependent mixed additions have run, and a G2 addition is ~15 us for a lone wave (256 of them: 4 ms), so
+  // a sort whose result also feeds a G2 accumulation (the prover's B query) uses a quarter of that; buckets
+  // longer than K0 continue in the partial-sum levels.
+  double avg = (double)n / (double)p.Nb;
   uint32_t k0 = 32;
-  while ((double)k0 < (double)n * p.W / (4.0 * lanes) && k0 < 256) k0 <<= 1;
+  while (k0 < 2 * avg && k0 < 256) k0 <<= 1;
+  if (for_g2 && k0 > 32) k0 = k0 >= 128 ? k0 / 4 : 32;
   p.K0 = k0;
   return p;
 }
@@ -560,9 +562,9 @@ inline void lane_reserve(Lane& lane, size_t need) {
 // The arena is reset here; the result stays valid until the lane's next msm_sort_phase. With
 // sync_at_end the stream is synchronised on return, so other lanes may read the result.
 inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int force_c,
-                                size_t (*extra)(const MsmPlan&), bool sync_at_end = false) {
+                                size_t (*extra)(const MsmPlan&), bool sync_at_end = false, bool for_g2 = false) {
   MsmSorted sr;
-  sr.p = msm_make_plan(n, force_c);
+  sr.p = msm_make_plan(n, force_c, for_g2);
   const MsmPlan& p = sr.p;
   // entry positions are 32-bit: n * W (+ a few per-bucket slots) must stay below 2^32
   if ((uint64_t)p.n * p.W + p.TB >= 0xffff0000ull) throw HipError("msm: n * windows exceeds the 32-bit entry index");
@@ -754,7 +756,8 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
 template <class F>
 inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
                           int force_c = 0, float* accum_ms = nullptr) {
-  MsmSorted sr = msm_sort_phase(lane, d_scalars, n, force_c, &msm_accum_workspace_bytes<F>);
+  MsmSorted sr = msm_sort_phase(lane, d_scalars, n, force_c, &msm_accum_workspace_bytes<F>, false,
+                                FieldBytes<F>::N > 32);
   msm_accum_phase<F>(lane, sr, d_bases, window_sums_host, true, accum_ms);
   return sr.p;
 }

@@ -6,12 +6,12 @@ void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void
                 float* ms2) {
   msm_run<Fq, HFq>(ctx, lane_id, d_bases, d_scalars, n, out, ms2);
 }
-MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n) {
+MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n, bool for_g2) {
   // the sorting lane also accumulates a G1 array afterwards: reserve room for that in the same arena
   MsmSorted* sr = new MsmSorted();
   try {
     *sr = msm_sort_phase(ctx->dev.lanes[lane_id], d_scalars, (size_t)n, ctx->opt_msm_c, &msm_accum_workspace_bytes<Fq>,
-                         true);
+                         true, for_g2);
   } catch (...) {
     delete sr;
     throw;

@@ -541,7 +541,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
     MsmSorted* sr = nullptr;
     try {
       gather(2, zk->qB);
-      sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt);
+      sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true);
       sorted_promise.set_value(sr);
     } catch (...) {
       sorted_promise.set_exception(std::current_exception());

@@ -50,7 +50,9 @@ void gen_bases_g2(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le
 // shared-sort form (prover: the A, B1 and B2 queries use the same witness scalars): sort once on `lane`
 // (stream synchronised on return), then accumulate each base array on its own lane.
 struct MsmSorted;
-MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n);  // delete with msm_sorted_free
+// for_g2: the result also feeds a G2 accumulation (shorter pieces: a G2 addition has 3x the latency)
+MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n,
+                        bool for_g2 = false);  // delete with msm_sorted_free
 void msm_sorted_free(MsmSorted* sr);
 void msm_accum_g1(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
                   uint8_t* out, float* ms2);
