@@ -190,7 +190,7 @@ def test_prover_cli_server_mode(zk, tmp_path):
         assert (tmp_path / "proof_s.json").read_text() == g["proof_snarkjs.json"]
         assert (tmp_path / "public_s.json").read_text() == g["public_snarkjs.json"]
         log = (tmp_path / "prover.sock.log").read_text()
-        assert log.count("zkey load") == 1 and log.count("zkey cached") == 1      # uploaded once, reused once
+        assert log.count("| zkey load ") == 1 and log.count("| zkey cached,") == 1   # uploaded once, reused once
         # a failing request: rapidsnark's message, exit code 1, no output files, and the server stays up
         rc = run("short.wtns", "bad.json", "bad_public.json")
         assert rc.returncode == 1 and "Invalid witness length" in rc.stderr
@@ -208,7 +208,7 @@ def test_prover_cli_server_mode(zk, tmp_path):
         os.utime(tmp_path / "circuit_final.zkey", ns=(1, 1))
         rc = run("witness.wtns", "proof3.json", "public3.json")
         assert rc.returncode == 0 and (tmp_path / "proof3.json").read_text() == g["proof_rapidsnark.json"]
-        assert (tmp_path / "prover.sock.log").read_text().count("zkey load") == 2
+        assert (tmp_path / "prover.sock.log").read_text().count("| zkey load ") == 2
     finally:
         subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
     for _ in range(100):

@@ -16,7 +16,9 @@ namespace zkpoa {
 class FastUploader {
  public:
   static constexpr int kThreads = 6;
-  static constexpr size_t kChunk = 8u << 20;  // 8 MiB per buffer, two per thread
+  // 2 MiB per buffer, two per thread: large enough for full-rate DMA, and pinning the staging memory is a
+  // start-up cost that a one-shot prover pays every time (12 x 8 MiB cost ~60 ms, 12 x 2 MiB ~15 ms)
+  static constexpr size_t kChunk = 2u << 20;
 
   ~FastUploader() { release(); }
 
@@ -37,15 +39,16 @@ class FastUploader {
         try {
           ZK_HIP(hipSetDevice(device));
           Slot& s = slots_[t];
+          hipStream_t stream = streams_[t % kStreams];
           int b = 0;
           for (size_t off = lo; off < hi; off += kChunk, b ^= 1) {
             size_t len = hi - off < kChunk ? hi - off : kChunk;
             ZK_HIP(hipEventSynchronize(s.done[b]));  // the DMA that last used this buffer has finished
             memcpy(s.pinned[b], reinterpret_cast<const char*>(src) + off, len);
-            ZK_HIP(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, s.pinned[b], len, hipMemcpyHostToDevice, s.stream));
-            ZK_HIP(hipEventRecord(s.done[b], s.stream));
+            ZK_HIP(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, s.pinned[b], len, hipMemcpyHostToDevice, stream));
+            ZK_HIP(hipEventRecord(s.done[b], stream));
           }
-          ZK_HIP(hipStreamSynchronize(s.stream));
+          for (int k = 0; k < 2; k++) ZK_HIP(hipEventSynchronize(s.done[k]));
         } catch (...) {
           errs[t] = std::current_exception();
         }
@@ -64,8 +67,10 @@ class FastUploader {
         s.pinned[b] = nullptr;
         s.done[b] = nullptr;
       }
-      if (s.stream) (void)hipStreamDestroy(s.stream);
-      s.stream = nullptr;
+    }
+    for (auto& st : streams_) {
+      if (st) (void)hipStreamDestroy(st);
+      st = nullptr;
     }
     ready_ = false;
   }
@@ -74,20 +79,25 @@ class FastUploader {
   struct Slot {
     void* pinned[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
-    hipStream_t stream = nullptr;
   };
+  // Few streams: every HIP stream brings up its own hardware queue on first use (~10 ms each, measured:
+  // six streams cost a one-shot prover ~60 ms before the first byte moved); the copies of all threads
+  // interleave on two.
+  static constexpr int kStreams = 2;
   Slot slots_[kThreads];
+  hipStream_t streams_[kStreams] = {};
   bool ready_ = false;
 
   void ensure(int device) {
     if (ready_) return;
     ZK_HIP(hipSetDevice(device));
-    for (auto& s : slots_) {
-      ZK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (auto& st : streams_) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int t = 0; t < kThreads; t++) {
+      Slot& s = slots_[t];
       for (int b = 0; b < 2; b++) {
         ZK_HIP(hipHostMalloc(&s.pinned[b], kChunk, hipHostMallocDefault));
         ZK_HIP(hipEventCreate(&s.done[b]));
-        ZK_HIP(hipEventRecord(s.done[b], s.stream));
+        ZK_HIP(hipEventRecord(s.done[b], streams_[t % kStreams]));
       }
     }
     ready_ = true;

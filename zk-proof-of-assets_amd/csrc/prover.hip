@@ -84,9 +84,15 @@ const uint8_t kR[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x
 
 void* dev_upload(zkpoa_context* ctx, const void* src, size_t bytes) {
   void* d = nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   ZK_HIP(hipMalloc(&d, bytes ? bytes : 1));
+  auto t1 = std::chrono::steady_clock::now();
   try {
     if (bytes) ctx->uploader.upload(d, src, bytes, ctx->dev.device);
+    if (getenv("ZKPOA_VERBOSE") && bytes > (16u << 20))
+      fprintf(stderr, "zkpoa:   upload %.0f MB: hipMalloc %.1f ms, copy %.1f ms\n", bytes / 1e6,
+              std::chrono::duration<double, std::milli>(t1 - t0).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   } catch (...) {
     (void)hipFree(d);
     throw;
@@ -342,6 +348,15 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     check_split(zk.get(), rank, world);
     set_split(zk.get(), rank, world);
   }
+  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  auto tph = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {   // ZKPOA_VERBOSE: where a key load spends its time
+    if (!verbose) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "zkpoa: zkey load: %-34s %7.1f ms\n", what,
+            std::chrono::duration<double, std::milli>(now - tph).count());
+    tph = now;
+  };
   try {
     // each rank uploads only its byte range of every point section
     zk->dA = dev_upload(ctx, s5.p + zk->wlo * 64, zk->wcnt * 64);
@@ -366,9 +381,12 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     } else {
       zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
     }
+    phase("point sections 5-9 -> HBM");
     queries_compact(ctx, zk.get(), zk->wcnt);
+    phase("A / B queries without infinity");
     hipStream_t st = ctx->dev.lanes[0].stream;
     void* d_recs = dev_upload(ctx, s4.p + 4, zk->nCoefs * 44);
+    phase("coefficient section -> HBM");
     try {
       build_csr(ctx, zk.get(), d_recs, split);
     } catch (...) {
@@ -376,9 +394,11 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
       throw;
     }
     (void)hipFree(d_recs);
+    phase("CSR of the coefficients");
     ntt_prepare(ctx, st, zk->power);
     if (split) ntt_prepare(ctx, st, zk->power - zk->split_log);
     ZK_HIP(hipStreamSynchronize(st));
+    phase("NTT tables");
   } catch (...) {
     zk->release();
     throw;
