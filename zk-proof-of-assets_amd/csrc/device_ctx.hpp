@@ -4,7 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -62,6 +67,7 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
     int lo = 0, hi = 0;  // numerically lower = higher priority
     ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     int prio = level >= 2 ? hi : (level == 1 ? (lo + hi) / 2 : lo);
+    // creating the stream is the expensive part (10-50 ms: a hardware queue comes up with it)
     ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio));
     pinned_cap = 1 << 20;
     ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
@@ -88,8 +94,18 @@ struct DeviceCtx {
   bool ok = false;
   // last-run kernel timing (HIP events on the lane's stream), for bench.py's roofline object
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::thread bg_;
+  std::mutex bg_mutex_;
+  std::exception_ptr bg_err_;
 
   void init(int dev) {
+    const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+    auto now_ms = [] {
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+    };
+    double t0 = now_ms();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
@@ -100,13 +116,41 @@ struct DeviceCtx {
     hipDeviceProp_t prop;
     ZK_HIP(hipGetDeviceProperties(&prop, dev));
     num_cu = prop.multiProcessorCount;
+    double t1 = now_ms();
     // lane 0 carries the prover's critical path (H-scalar chain -> H MSM): highest stream priority
     // and lane 3 (the G2 MSM, the longest of the witness MSMs) the middle one.
-    for (int i = 0; i < kLanes; i++) lanes[i].init(i == 0 ? 2 : (i == 3 ? 1 : 0));
+    // A stream with its pinned buffer and events costs ~12 ms to create: lane 0 now, the others on a background
+    // thread (they are first needed by the MSMs of a prove, after the key has been uploaded) -> wait_lanes().
+    lanes[0].init(2);
+    bg_ = std::thread([this] {
+      try {
+        ZK_HIP(hipSetDevice(device));
+        for (int i = 1; i < kLanes; i++) lanes[i].init(i == 3 ? 1 : 0);
+      } catch (...) {
+        bg_err_ = std::current_exception();
+      }
+    });
+    if (verbose)
+      fprintf(stderr, "zkpoa: HIP runtime up in %.1f ms, first lane in %.1f ms (the other %d in the background)\n",
+              t1 - t0, now_ms() - t1, kLanes - 1);
     ok = true;
+  }
+  // every lane other than 0 may only be used after this (cheap once the background thread has been joined)
+  void wait_lanes() {
+    std::lock_guard<std::mutex> lk(bg_mutex_);
+    if (bg_.joinable()) bg_.join();
+    if (bg_err_) {
+      std::exception_ptr e = bg_err_;
+      bg_err_ = nullptr;
+      std::rethrow_exception(e);
+    }
   }
   void destroy() {
     if (!ok) return;
+    try {
+      wait_lanes();
+    } catch (...) {
+    }
     (void)hipSetDevice(device);
     for (auto& l : lanes) l.destroy();
     ok = false;

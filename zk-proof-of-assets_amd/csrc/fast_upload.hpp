@@ -22,12 +22,15 @@ class FastUploader {
 
   ~FastUploader() { release(); }
 
-  void upload(void* dst, const void* src, size_t bytes, int device) {
+  // `stream`: an existing stream of the caller that is idle during the upload (the context's lane 0). Creating
+  // a HIP stream costs 10-50 ms (it brings up a hardware queue), which a one-shot prover pays on every run, so
+  // the uploader owns none: the copies of all threads interleave on the one stream at full PCIe rate.
+  void upload(void* dst, const void* src, size_t bytes, int device, hipStream_t stream) {
     if (bytes < (4u << 20)) {  // small: not worth the threads
       ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
       return;
     }
-    ensure(device);
+    ensure(device, stream);
     std::vector<std::thread> th;
     std::vector<std::exception_ptr> errs(kThreads);
     size_t per = ((bytes / kThreads) + 4095) & ~size_t(4095);
@@ -35,11 +38,10 @@ class FastUploader {
       size_t lo = (size_t)t * per;
       if (lo >= bytes) break;
       size_t hi = lo + per < bytes ? lo + per : bytes;
-      th.emplace_back([this, t, lo, hi, dst, src, device, &errs] {
+      th.emplace_back([this, t, lo, hi, dst, src, device, stream, &errs] {
         try {
           ZK_HIP(hipSetDevice(device));
           Slot& s = slots_[t];
-          hipStream_t stream = streams_[t % kStreams];
           int b = 0;
           for (size_t off = lo; off < hi; off += kChunk, b ^= 1) {
             size_t len = hi - off < kChunk ? hi - off : kChunk;
@@ -68,10 +70,6 @@ class FastUploader {
         s.done[b] = nullptr;
       }
     }
-    for (auto& st : streams_) {
-      if (st) (void)hipStreamDestroy(st);
-      st = nullptr;
-    }
     ready_ = false;
   }
 
@@ -80,24 +78,18 @@ class FastUploader {
     void* pinned[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
   };
-  // Few streams: every HIP stream brings up its own hardware queue on first use (~10 ms each, measured:
-  // six streams cost a one-shot prover ~60 ms before the first byte moved); the copies of all threads
-  // interleave on two.
-  static constexpr int kStreams = 2;
   Slot slots_[kThreads];
-  hipStream_t streams_[kStreams] = {};
   bool ready_ = false;
 
-  void ensure(int device) {
+  void ensure(int device, hipStream_t stream) {
     if (ready_) return;
     ZK_HIP(hipSetDevice(device));
-    for (auto& st : streams_) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (int t = 0; t < kThreads; t++) {
       Slot& s = slots_[t];
       for (int b = 0; b < 2; b++) {
         ZK_HIP(hipHostMalloc(&s.pinned[b], kChunk, hipHostMallocDefault));
         ZK_HIP(hipEventCreate(&s.done[b]));
-        ZK_HIP(hipEventRecord(s.done[b], streams_[t % kStreams]));
+        ZK_HIP(hipEventRecord(s.done[b], stream));
       }
     }
     ready_ = true;

@@ -10,6 +10,7 @@ MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, 
   // the sorting lane also accumulates a G1 array afterwards: reserve room for that in the same arena
   MsmSorted* sr = new MsmSorted();
   try {
+    if (lane_id) ctx->dev.wait_lanes();
     *sr = msm_sort_phase(ctx->dev.lanes[lane_id], d_scalars, (size_t)n, ctx->opt_msm_c, &msm_accum_workspace_bytes<Fq>,
                          true, for_g2);
   } catch (...) {

@@ -8,6 +8,7 @@ template <class F, class HF>
 // ms2 (optional): [0] = device time of the whole MSM, [1] = its level-0 bucket-accumulation kernel
 void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
              float* ms2) {
+  if (lane_id) ctx->dev.wait_lanes();
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
   float acc_ms = 0;
@@ -30,6 +31,7 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
 template <class F, class HF>
 void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool own_arena, const void* d_bases,
                    uint8_t* out, float* ms2) {
+  if (lane_id) ctx->dev.wait_lanes();
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
   float acc_ms = 0;

@@ -88,7 +88,7 @@ void* dev_upload(zkpoa_context* ctx, const void* src, size_t bytes) {
   ZK_HIP(hipMalloc(&d, bytes ? bytes : 1));
   auto t1 = std::chrono::steady_clock::now();
   try {
-    if (bytes) ctx->uploader.upload(d, src, bytes, ctx->dev.device);
+    if (bytes) ctx->uploader.upload(d, src, bytes, ctx->dev.device, ctx->dev.lanes[0].stream);
     if (getenv("ZKPOA_VERBOSE") && bytes > (16u << 20))
       fprintf(stderr, "zkpoa:   upload %.0f MB: hipMalloc %.1f ms, copy %.1f ms\n", bytes / 1e6,
               std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -512,6 +512,7 @@ WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
 // in zk->d_witness (device). The H-scalar chain runs in full on every rank (replicated).
 void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) {
   auto t0 = std::chrono::steady_clock::now();
+  ctx->dev.wait_lanes();
   Lane& l0 = ctx->dev.lanes[0];
   uint8_t* outA = out;
   uint8_t* outB1 = out + 64;
@@ -685,7 +686,7 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
   Lane& l0 = ctx->dev.lanes[0];
   (void)l0;
-  ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
+  ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
   prove_core(ctx, zk, r_le, s_le, proof_points);
   memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
 }
@@ -1082,7 +1083,7 @@ extern "C" int zkpoa_witness_load(zkpoa_context* ctx, const zkpoa_zkey* zkey, co
                                                            std::to_string(zkey->nVars) + ", witness: " + std::to_string(w.n));
     if (public_le && public_capacity < (unsigned long)zkey->nPublic * 32)
       throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
-    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
+    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
     zkey->h_ready = false;
     if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
   }
@@ -1147,7 +1148,7 @@ extern "C" int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, 
     if (zkey->split_world > 1)
       throw ProverError(PROVER_ERROR, "split chain: use zkpoa_witness_load, zkpoa_split_stage1/2/3, then "
                                       "zkpoa_prove_partials_device with a NULL witness");
-    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device);
+    ctx->uploader.upload(zkey->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
     prove_partials(ctx, zkey, partials);
     if (public_le) memcpy(public_le, w.values + 32, (size_t)zkey->nPublic * 32);
   }
