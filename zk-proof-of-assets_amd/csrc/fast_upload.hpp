@@ -64,12 +64,13 @@ class FastUploader {
   void release() {
     for (auto& s : slots_) {
       for (int b = 0; b < 2; b++) {
-        if (s.pinned[b]) (void)hipHostFree(s.pinned[b]);
         if (s.done[b]) (void)hipEventDestroy(s.done[b]);
         s.pinned[b] = nullptr;
         s.done[b] = nullptr;
       }
     }
+    if (block_) (void)hipHostFree(block_);
+    block_ = nullptr;
     ready_ = false;
   }
 
@@ -79,15 +80,17 @@ class FastUploader {
     hipEvent_t done[2] = {nullptr, nullptr};
   };
   Slot slots_[kThreads];
+  void* block_ = nullptr;
   bool ready_ = false;
 
   void ensure(int device, hipStream_t stream) {
     if (ready_) return;
     ZK_HIP(hipSetDevice(device));
+    ZK_HIP(hipHostMalloc(&block_, (size_t)kThreads * 2 * kChunk, hipHostMallocDefault));   // one pinning call
     for (int t = 0; t < kThreads; t++) {
       Slot& s = slots_[t];
       for (int b = 0; b < 2; b++) {
-        ZK_HIP(hipHostMalloc(&s.pinned[b], kChunk, hipHostMallocDefault));
+        s.pinned[b] = static_cast<char*>(block_) + ((size_t)t * 2 + b) * kChunk;
         ZK_HIP(hipEventCreate(&s.done[b]));
         ZK_HIP(hipEventRecord(s.done[b], stream));
       }
