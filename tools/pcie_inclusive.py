@@ -22,7 +22,7 @@ ctx.msm_g1(bases, scal, n)
 t0 = time.perf_counter()
 for _ in range(5): ctx.msm_g1(bases, scal, n)
 t = (time.perf_counter() - t0) / 5
-print("host-buffer zkpoa_msm_g1 2^20 (96 MiB upload per call, via ctypes copies): %.2f ms/MSM = %.1f M pts/s" % (t * 1e3, n / t / 1e6))
+print("host-buffer zkpoa_msm_g1 2^20 (96 MiB of pageable host memory uploaded per call): %.2f ms/MSM = %.1f M pts/s" % (t * 1e3, n / t / 1e6))
 
 # 2. zkey file image at the layer_one(2) shape -> load + prove, and the CLI
 k, m, npub = 21, 2083343, 1

@@ -112,8 +112,9 @@ extern "C" int zkpoa_msm_g1(zkpoa_context* ctx, const void* bases, const void* s
   ZK_API_BEGIN(ctx)
   check_n(n);
   DevBuf db(n * 64), ds(n * 32);
-  ZK_HIP(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
-  ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  // pageable host buffers: the multi-threaded pinned-staging uploader (a plain hipMemcpy stages at ~4 GB/s)
+  ctx->uploader.upload(db.p, bases, n * 64, ctx->dev.device, ctx->dev.lanes[0].stream);
+  ctx->uploader.upload(ds.p, scalars, n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
   msm_run_g1(ctx, 0, db.p, ds.p, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
@@ -121,8 +122,9 @@ extern "C" int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* s
   ZK_API_BEGIN(ctx)
   check_n(n);
   DevBuf db(n * 128), ds(n * 32);
-  ZK_HIP(hipMemcpy(db.p, bases, n * 128, hipMemcpyHostToDevice));
-  ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  // pageable host buffers: the multi-threaded pinned-staging uploader (a plain hipMemcpy stages at ~4 GB/s)
+  ctx->uploader.upload(db.p, bases, n * 128, ctx->dev.device, ctx->dev.lanes[0].stream);
+  ctx->uploader.upload(ds.p, scalars, n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
   msm_run_g2(ctx, 0, db.p, ds.p, n, out, ctx->ms);
   ZK_API_END(ctx)
 }
