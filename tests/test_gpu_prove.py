@@ -242,6 +242,35 @@ def test_python_host_mirror_groth16_prove(zk, tmp_path):
     assert g16.verify(vkey, public, proof)
 
 
+@pytest.mark.parametrize("cache", ["0", "1", "2"])
+def test_zkey_file_cache_alternating_keys(zk, tmp_path, monkeypatch, cache):
+    """groth16_prover_zkey_file keeps proving keys resident (ZKPOA_KEY_CACHE entries, LRU): alternating between
+    two key files must give each file's own golden proof whether the cache is off, thrashing (1) or holds both."""
+    monkeypatch.setenv("ZKPOA_KEY_CACHE", cache)
+    cases = {}
+    for tag in ("n8", "n128"):
+        g = golden_case(tag)
+        (tmp_path / (tag + ".zkey")).write_bytes(g["circuit.zkey"])
+        (tmp_path / (tag + ".wtns")).write_bytes(g["witness.wtns"])
+        cases[tag] = (g, json.loads(g["rs.json"]))
+    for i, tag in enumerate(["n8", "n128", "n8", "n8", "n128", "n128", "n8"]):
+        g, rs = cases[tag]
+        monkeypatch.setenv("ZKPOA_R", rs["r"])
+        monkeypatch.setenv("ZKPOA_S", rs["s"])
+        zk.groth16_prove(str(tmp_path / (tag + ".zkey")), str(tmp_path / (tag + ".wtns")),
+                         str(tmp_path / ("p%d.json" % i)), str(tmp_path / ("u%d.json" % i)))
+        assert (tmp_path / ("p%d.json" % i)).read_text() == g["proof_rapidsnark.json"]
+        assert (tmp_path / ("u%d.json" % i)).read_text() == g["public_rapidsnark.json"]
+    # a key file rewritten in place (same path, new content) is a different key
+    g8, rs8 = cases["n8"]
+    (tmp_path / "n128.zkey").write_bytes(g8["circuit.zkey"])
+    monkeypatch.setenv("ZKPOA_R", rs8["r"])
+    monkeypatch.setenv("ZKPOA_S", rs8["s"])
+    zk.groth16_prove(str(tmp_path / "n128.zkey"), str(tmp_path / "n8.wtns"), str(tmp_path / "px.json"),
+                     str(tmp_path / "ux.json"))
+    assert (tmp_path / "px.json").read_text() == g8["proof_rapidsnark.json"]
+
+
 # ---- device-resident synthetic key with known discrete logs (SURVEY.md 8d) --------------------------------
 @pytest.mark.parametrize("witness_like", [False, True])
 def test_synthetic_circuit_prove_known_dlog(ctx, zk, witness_like):
