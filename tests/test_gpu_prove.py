@@ -504,3 +504,29 @@ def test_prove_degenerate_witness(ctx, zk):
         key.close()
     proof, _ = g16.prove(zkey, wt, 0, 0)
     assert _pts_to_proof(pts) == proof
+
+
+# ---- the real multi-process path: two ranks sharing this box's GPU, gloo collectives (rehearsal mode) ----------
+@pytest.mark.parametrize("extra", [[], ["--replicated-chain"]])
+def test_two_process_sharded_prove_rehearsal(extra):
+    """bench.py's N = 2 prove exactly as the driver launches it (torch.distributed.run, one process per rank),
+    except that both ranks use the one GPU and the exchanges go through the host (ZKPOA_BENCH_REHEARSE=1):
+    split shards per process, the three stages around two all-to-alls (or the replicated chain), all-gather of
+    the partial points, host assembly -- bench.py itself checks the proof against the known discrete logs."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZKPOA_BENCH_REHEARSE="1")
+    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "prove_2p16"] + extra,
+                        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    line = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["metric"] == "Groth16 proofs/sec"
+    assert ("replicated" if extra else "split") in line["config"]["parallelism"]
+    assert "REHEARSAL" in line["data"]
