@@ -109,6 +109,124 @@ def test_h_scalars_mid_size_vs_c_oracle(ctx, mid_circuit):
     assert got == co.h_scalars(zkey[p4:p4 + l4], wit, 7000, 13)
 
 
+def _long_row_section(rng, n_vars, log_domain, n_long=40):
+    """zkey section 4 payload for an R1CS whose row lengths are skewed the way real circuits are: most constraints
+    have 1-3 terms per side, a few dozen have hundreds (a Num2Bits sum, a carry chain), one has 1500, some are
+    empty, and the 32/33-term boundary of the wave kernel is hit from both sides."""
+    domain = 1 << log_domain
+    recs = []
+    lengths = {}
+    special = rng.sample(range(domain - 8), n_long + 6)
+    for c in special[:n_long]:
+        lengths[c] = (rng.randrange(60, 400), rng.randrange(0, 300))
+    lengths[special[n_long]] = (1500, 2)
+    lengths[special[n_long + 1]] = (30, 2)       # 32 in total: still the thread kernel
+    lengths[special[n_long + 2]] = (31, 2)       # 33: the wave kernel
+    lengths[special[n_long + 3]] = (0, 64)       # long B side only
+    lengths[special[n_long + 4]] = (33, 0)
+    lengths[special[n_long + 5]] = (0, 0)
+    for c in range(domain - 8):
+        la, lb = lengths.get(c, (rng.randrange(0, 4), rng.randrange(0, 3)))
+        for m, cnt in ((0, la), (1, lb)):
+            for _ in range(cnt):
+                recs.append(struct.pack("<III", m, c, rng.randrange(n_vars)) + le(rng.randrange(R)))
+    rng.shuffle(recs)                              # file order is arbitrary
+    return struct.pack("<I", len(recs)) + b"".join(recs)
+
+
+def test_h_scalars_long_rows_vs_c_oracle(ctx):
+    rng = random.Random(77)
+    n_vars, k = 3000, 12
+    sec = _long_row_section(rng, n_vars, k)
+    wit = b"".join(le(rng.randrange(R)) for _ in range(n_vars))
+    assert ctx.h_scalars(sec, wit, n_vars, k) == co.h_scalars(sec, wit, n_vars, k)
+
+
+@pytest.fixture(scope="module")
+def long_row_circuit():
+    """Satisfiable R1CS with realistic skew: 500 short constraints plus sums of 40..300 terms on the A side
+    (and a few on the B side) -- (sum a_i w_i) * (sum b_j w_j) = w_e with w_e filled forward."""
+    rng = random.Random(4242)
+    nVars, nPublic = 900, 2
+    cons, w = g16.random_circuit(rng, nVars - 60, nPublic, 500)
+    w = w + [0] * 60
+    for i in range(60):
+        e = nVars - 60 + i
+        la = rng.randrange(40, 300)
+        lb = rng.choice([1, 1, 1, 2, 50])
+        A = {rng.randrange(0, nVars - 60): rng.randrange(1, R) for _ in range(la)}
+        B = {rng.randrange(0, nVars - 60): rng.randrange(1, R) for _ in range(lb)}
+        va = sum(k * w[s] for s, k in A.items()) % R
+        vb = sum(k * w[s] for s, k in B.items()) % R
+        w[e] = va * vb % R
+        cons.append((A, B, {e: 1}))
+    rng.shuffle(cons)
+    tox = {k: rng.randrange(1, R) for k in ("tau", "alpha", "beta", "gamma", "delta")}
+    zkey, vk = g16.synthetic_setup(nVars, nPublic, cons, tox,
+                                   g1_batch=lambda s: co.fixed_base_g1(b"".join(le(k) for k in s), 8),
+                                   g2_batch=lambda s: co.fixed_base_g2(b"".join(le(k) for k in s), 8))
+    return zkey, vk, g16.write_wtns(w), nPublic
+
+
+def test_prove_long_rows_verifies_and_matches_oracle(ctx, long_row_circuit):
+    zkey, vk, wt, n_pub = long_row_circuit
+    rng = random.Random(5)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    key = ctx.load_zkey(zkey)
+    try:
+        pts, pub = ctx.prove(key, wt, r_, s_)
+    finally:
+        key.close()
+    exp, exp_pub = co.prove(zkey, wt, r_, s_, nthreads=8)
+    assert pts == exp and pub == exp_pub
+    assert g16.verify(vk, [rd(pub, i) for i in range(n_pub)], g16.proof_to_obj(_pts_to_proof(pts)))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_split_chain_long_rows(ctx, zk, long_row_circuit, world):
+    """the wave-per-constraint path inside the split chain: rank-local CSR (keeps its own long rows)"""
+    zkey, _, wt, _ = long_row_circuit
+    full = ctx.load_zkey(zkey)
+    try:
+        want, pub = ctx.prove(full, wt, 3, 4)
+        header = full.header()
+        domain = full.info()[2]
+    finally:
+        full.close()
+    keys = [ctx.load_zkey_shard_split(zkey, r, world) for r in range(world)]
+    try:
+        for k in keys:
+            ctx.witness_load(k, wt)
+        parts = _split_chain_partials(ctx, keys, world, domain)
+        assert zk.prove_assemble(header, zk.sum_partials(parts), 3, 4) == want
+    finally:
+        for k in keys:
+            k.close()
+    # ... and a fully resident key re-pointed rank by rank (full CSR walked with stride G, long list filtered)
+    import torch
+    full = ctx.load_zkey(zkey)
+    try:
+        ctx.witness_load(full, wt)
+        mb = domain // world * 32
+        send = torch.zeros((world, 3, mb), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            full.set_shard_split(r, world)
+            ctx.split_stage1(full, None, send[r].data_ptr())
+        recv = _virtual_all_to_all(send, world)
+        for r in range(world):
+            full.set_shard_split(r, world)
+            ctx.split_stage2(full, recv[r].data_ptr(), send[r].data_ptr())
+        recv = _virtual_all_to_all(send, world)
+        parts = []
+        for r in range(world):
+            full.set_shard_split(r, world)
+            ctx.split_stage3(full, recv[r].data_ptr())
+            parts.append(ctx.prove_partials_device(full, None))
+        assert zk.prove_assemble(header, zk.sum_partials(parts), 3, 4) == want
+    finally:
+        full.close()
+
+
 # ---- error behaviour of the boundary (scripts/lib/error_handling.sh relies on a non-zero exit) ------------
 def test_wrong_witness_length_code(ctx, zk):
     g = golden_case("n8")

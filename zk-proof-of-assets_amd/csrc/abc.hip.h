@@ -78,9 +78,14 @@ ZK_DEV Fr abc_row_sum(const uint32_t* __restrict__ row_ptr, uint32_t row, const 
   return acc;
 }
 
+// A constraint whose two rows hold more than kLongRow coefficients (a Num2Bits sum, a big-integer carry chain:
+// hundreds of terms) would keep one lane busy for hundreds of iterations while its 63 neighbours wait, so such
+// constraints are listed once per key and handled one WAVE per constraint (abc_long_rows_kernel).
+constexpr uint32_t kLongRow = 32;
+
 // one thread per output t < count: CSR row pair of constraint c = row_off + row_stride * t ->
 // A_T[t], B_T[t], C_T[t] = A (x) B. (row_off, row_stride) = (0, 1) walks the whole CSR; a rank of the
-// split chain walks its cyclic rows of a full CSR with (rank, world).
+// split chain walks its cyclic rows of a full CSR with (rank, world). Long constraints are left to the wave kernel.
 static __global__ __launch_bounds__(256) void abc_rows_kernel(const uint32_t* __restrict__ row_ptr,
                                                               const uint32_t* __restrict__ sig,
                                                               const void* __restrict__ vals,
@@ -91,11 +96,66 @@ static __global__ __launch_bounds__(256) void abc_rows_kernel(const uint32_t* __
   uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= count) return;
   uint32_t c = row_off + row_stride * t;
+  if (row_ptr[2u * c + 2u] - row_ptr[2u * c] > kLongRow) return;
   Fr a = abc_row_sum(row_ptr, 2u * c, sig, vals, witness);
   Fr b = abc_row_sum(row_ptr, 2u * c + 1u, sig, vals, witness);
   store_field(reinterpret_cast<char*>(A) + 32 * (size_t)t, a);
   store_field(reinterpret_cast<char*>(B) + 32 * (size_t)t, b);
   store_field(reinterpret_cast<char*>(C) + 32 * (size_t)t, a * b);
+}
+
+// key load: list the long constraints (order irrelevant). cnt[0] = how many; list may be null (count only)
+static __global__ __launch_bounds__(256) void abc_long_list_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows2,
+                                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ list) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= rows2 / 2u) return;
+  if (row_ptr[2u * c + 2u] - row_ptr[2u * c] > kLongRow) {
+    uint32_t slot = atomicAdd(cnt, 1u);
+    if (list) list[slot] = c;
+  }
+}
+
+// sum of one CSR row by a whole wave: lanes stride over the coefficients, then a shuffle tree
+ZK_DEV Fr abc_row_sum_wave(const uint32_t* __restrict__ row_ptr, uint32_t row, const uint32_t* __restrict__ sig,
+                           const void* __restrict__ vals, const void* __restrict__ witness, uint32_t lane) {
+  Fr acc = Fr::zero();
+  uint32_t b = row_ptr[row], e = row_ptr[row + 1];
+  for (uint32_t k = b + lane; k < e; k += 64u) {
+    Fr v = load_field<Fr>(reinterpret_cast<const char*>(vals) + 32 * (size_t)k);
+    Fr w = load_field<Fr>(reinterpret_cast<const char*>(witness) + 32 * (size_t)sig[k]);
+    acc = acc + v * w;
+  }
+  for (uint32_t off = 32u; off > 0u; off >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], off);
+    acc = acc + o;
+  }
+  return acc;   // complete in lane 0
+}
+
+// one wave per listed constraint c. Outputs go to index t: c itself, or for a rank of the split chain walking a
+// full CSR only the constraints with c = part (mod 2^log_parts), at t = c >> log_parts.
+static __global__ __launch_bounds__(256) void abc_long_rows_kernel(const uint32_t* __restrict__ row_ptr,
+                                                                   const uint32_t* __restrict__ sig,
+                                                                   const void* __restrict__ vals,
+                                                                   const void* __restrict__ witness,
+                                                                   const uint32_t* __restrict__ list, uint32_t n_long,
+                                                                   uint32_t log_parts, uint32_t part,
+                                                                   void* __restrict__ A, void* __restrict__ B,
+                                                                   void* __restrict__ C) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (wave >= n_long) return;
+  const uint32_t c = list[wave];
+  if ((c & ((1u << log_parts) - 1u)) != part) return;
+  const uint32_t t = c >> log_parts;
+  Fr a = abc_row_sum_wave(row_ptr, 2u * c, sig, vals, witness, lane);
+  Fr b = abc_row_sum_wave(row_ptr, 2u * c + 1u, sig, vals, witness, lane);
+  if (lane == 0) {
+    store_field(reinterpret_cast<char*>(A) + 32 * (size_t)t, a);
+    store_field(reinterpret_cast<char*>(B) + 32 * (size_t)t, b);
+    store_field(reinterpret_cast<char*>(C) + 32 * (size_t)t, a * b);
+  }
 }
 
 // P[i] = fromMontgomery(A[i] (x) B[i] - C[i]); out may be A

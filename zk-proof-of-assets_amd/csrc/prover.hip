@@ -110,6 +110,8 @@ struct zkpoa_zkey {
   Affine<HFq2> beta2, delta2;
   void *dA = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dC = nullptr, *dH = nullptr;
   uint32_t* d_row_ptr = nullptr;
+  uint32_t* d_long = nullptr;   // constraints with more than kLongRow coefficients (abc.hip.h), n_long of them
+  uint32_t n_long = 0;
   uint32_t* d_sig = nullptr;
   void* d_vals = nullptr;
   void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
@@ -163,17 +165,39 @@ struct zkpoa_zkey {
     if (owns_points)
       for (void* p : pts)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs};
+    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     qA.release();
     qB.release();
     dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = nullptr;
+    d_long = nullptr;
     d_row_ptr = d_sig = nullptr;
   }
 };
 
 namespace {
+
+// list of the constraints too long for one lane (key-dependent only); returns the count, *list owned by the caller
+uint32_t build_long_list(hipStream_t st, const uint32_t* d_row_ptr, uint32_t rows, uint32_t** list) {
+  DevBuf cnt(64);
+  *list = nullptr;
+  uint32_t n_long = 0;
+  const uint32_t grid = (rows / 2 + 255) / 256;
+  ZK_HIP(hipMemsetAsync(cnt.p, 0, 64, st));
+  hipLaunchKernelGGL(abc_long_list_kernel, dim3(grid), dim3(256), 0, st, d_row_ptr, rows, (uint32_t*)cnt.p,
+                     (uint32_t*)nullptr);
+  ZK_HIP(hipMemcpyAsync(&n_long, cnt.p, 4, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipMalloc(reinterpret_cast<void**>(list), (size_t)(n_long ? n_long : 1) * 4));
+  if (n_long) {
+    ZK_HIP(hipMemsetAsync(cnt.p, 0, 64, st));
+    hipLaunchKernelGGL(abc_long_list_kernel, dim3(grid), dim3(256), 0, st, d_row_ptr, rows, (uint32_t*)cnt.p, *list);
+    ZK_HIP(hipStreamSynchronize(st));
+  }
+  ZK_HIP(hipGetLastError());
+  return n_long;
+}
 
 // CSR of the coefficient list by output row (2*c + m); d_recs = device copy of the 44-byte records.
 // Also allocates the A/B/C work area and the witness buffer. With split_log > 0 (split chain loaded from a
@@ -217,6 +241,7 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool loca
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
   }
+  zk->n_long = build_long_list(st, zk->d_row_ptr, rows, &zk->d_long);
 }
 
 // split chain: world must be a power of two <= 8 with world^2 <= domain (every rank owns whole slots of
@@ -408,13 +433,17 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
 
 // H-scalar chain on lane.stream: A_T,B_T,C_T -> odd coset -> P (standard form) left in abc[0 .. n)
 void h_chain(zkpoa_context* ctx, hipStream_t st, const uint32_t* row_ptr, const uint32_t* sig, const void* vals,
-             const void* d_witness, uint32_t domain, uint32_t power, void* d_abc) {
+             const uint32_t* long_list, uint32_t n_long, const void* d_witness, uint32_t domain, uint32_t power,
+             void* d_abc) {
   char* A = reinterpret_cast<char*>(d_abc);
   char* B = A + (size_t)domain * 32;
   char* C = B + (size_t)domain * 32;
   uint32_t grid = (domain + 255) / 256;
   hipLaunchKernelGGL(abc_rows_kernel, dim3(grid), dim3(256), 0, st, row_ptr, sig, vals, d_witness, domain, 0u, 1u,
                      (void*)A, (void*)B, (void*)C);
+  if (n_long)
+    hipLaunchKernelGGL(abc_long_rows_kernel, dim3((n_long + 3) / 4), dim3(256), 0, st, row_ptr, sig, vals, d_witness,
+                       long_list, n_long, 0u, 0u, (void*)A, (void*)B, (void*)C);
   ntt_to_odd_coset(ctx, st, A, power);
   ntt_to_odd_coset(ctx, st, B, power);
   ntt_to_odd_coset(ctx, st, C, power);
@@ -438,6 +467,12 @@ void split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
                      (const uint32_t*)zk->d_sig, (const void*)zk->d_vals, (const void*)zk->d_witness, M,
                      zk->csr_local ? 0u : zk->split_rank, zk->csr_local ? 1u : zk->split_world, (void*)A, (void*)B,
                      (void*)C);
+  if (zk->n_long)   // a rank-local CSR lists its own rows; a full CSR lists all, the kernel keeps c = rank (mod G)
+    hipLaunchKernelGGL(abc_long_rows_kernel, dim3((zk->n_long + 3) / 4), dim3(256), 0, st,
+                       (const uint32_t*)zk->d_row_ptr, (const uint32_t*)zk->d_sig, (const void*)zk->d_vals,
+                       (const void*)zk->d_witness, (const uint32_t*)zk->d_long, zk->n_long,
+                       zk->csr_local ? 0u : zk->split_log, zk->csr_local ? 0u : zk->split_rank, (void*)A, (void*)B,
+                       (void*)C);
   for (char* X : {A, B, C}) ntt_dif(ctx, st, X, kM, true);
   ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
@@ -577,7 +612,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   try {
     ZK_HIP(hipEventRecord(ctx->ev_a[5], l0.stream));
     if (!split)
-      h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_witness, zk->domain, zk->power, zk->d_abc);
+      h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_long, zk->n_long, zk->d_witness, zk->domain,
+              zk->power, zk->d_abc);
     ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
     if (split) {
       // the three stages left this rank's H scalars (odd-coset indices = rank mod G) in d_abc[0 .. n/G)
@@ -1327,12 +1363,21 @@ extern "C" int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned 
     ZK_HIP(hipStreamSynchronize(st));
     if (herr) throw ProverError(PROVER_ERROR, "h_scalars: coefficient record out of range");
     ntt_prepare(ctx, st, log_domain);
+    uint32_t* long_list = nullptr;
+    uint32_t n_long = build_long_list(st, (const uint32_t*)row_ptr.p, rows, &long_list);
     ZK_HIP(hipEventRecord(ctx->ev_a[5], st));
-    h_chain(ctx, st, (const uint32_t*)row_ptr.p, (const uint32_t*)sig.p, vals.p, wit.p, domain, log_domain, abc.p);
+    try {
+      h_chain(ctx, st, (const uint32_t*)row_ptr.p, (const uint32_t*)sig.p, vals.p, long_list, n_long, wit.p, domain,
+              log_domain, abc.p);
+    } catch (...) {
+      (void)hipFree(long_list);
+      throw;
+    }
     ZK_HIP(hipEventRecord(ctx->ev_b[5], st));
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
+    (void)hipFree(long_list);
     ZK_HIP(hipMemcpy(out, abc.p, (size_t)domain * 32, hipMemcpyDeviceToHost));
   }
   ZK_PROVER_CATCH(ctx)
