@@ -199,7 +199,8 @@ int zkpoa_sanitize_proof(const char* vkey_json, const char* public_json, const c
 /* Timings (ms, HIP events on the stream that ran the kernels) of the last call on this context.
  * id: 0 = whole device part of last MSM, 1 = its bucket-accumulation kernel (dominant kernel),
  *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total.
- * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto). */
+ * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto); key "msm_max_points" sets the
+ * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values). */
 float zkpoa_last_ms(const zkpoa_context* ctx, int id);
 int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value);
 

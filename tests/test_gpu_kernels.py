@@ -127,6 +127,24 @@ def test_msm_forced_windows(ctx, c):
     assert got == co.msm_g1(bases, sc, n, 8)
 
 
+def test_msm_chunked(ctx):
+    """An MSM over more points than one bucket sort may index (n x windows < 2^32: 2^27 points by default) runs
+    in chunks added on the host; "msm_max_points" forces that path at a size the oracle can check."""
+    rng = random.Random(31)
+    n = 3001
+    b1 = co.fixed_base_g1(b"".join(le(rng.randrange(R)) for _ in range(n)), 8)
+    b2 = co.fixed_base_g2(b"".join(le(rng.randrange(R)) for _ in range(700)), 8)
+    sc = _rand_scalars(rng, n, "witness")
+    ctx.set_option("msm_max_points", 1000)           # 3001 = 3 full chunks + 1 point
+    try:
+        got1 = ctx.msm_g1(b1, sc, n)
+        got2 = ctx.msm_g2(b2, sc[:700 * 32], 700)
+    finally:
+        ctx.set_option("msm_max_points", 0)
+    assert got1 == co.msm_g1(b1, sc, n, 8)
+    assert got2 == co.msm_g2(b2, sc[:700 * 32], 700, 8)
+
+
 def _dlog_setup(ctx, n, seed, group=1):
     import torch
     rng = random.Random(seed)

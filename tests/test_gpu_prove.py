@@ -66,6 +66,21 @@ def test_prove_random_r_s_verifies(ctx):
         assert g16.verify(vkey, [rd(pub, i) for i in range(n_pub)], g16.proof_to_obj(_pts_to_proof(p)))
 
 
+def test_prove_with_chunked_msms(ctx, zk):
+    """every MSM of the proof larger than one sort may take (forced to 40 points here): A, C and H run in chunks,
+    B1 / B2 cannot share a sort -- the proof must still be the golden one."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    key = ctx.load_zkey(g["circuit.zkey"])
+    ctx.set_option("msm_max_points", 40)
+    try:
+        pts, pub = ctx.prove(key, g["witness.wtns"], int(rs["r"]), int(rs["s"]))
+    finally:
+        ctx.set_option("msm_max_points", 0)
+        key.close()
+    assert zk.proof_to_json(pts, "rapidsnark") == g["proof_rapidsnark.json"]
+
+
 @pytest.fixture(scope="module")
 def mid_circuit():
     """2^13-constraint random circuit, setup through the C oracle's fixed-base generator."""

@@ -593,19 +593,28 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
     gather(1, zk->qA);
     msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1]);
   });
+  // (a B query beyond the 32-bit entry index of one sort cannot share it: two chunked MSMs instead)
+  const uint64_t sort_limit = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
+  const bool share_b = zk->qB.cnt <= sort_limit;
   std::thread tB1 = guarded(1, [&] {
     MsmSorted* sr = nullptr;
     try {
       gather(2, zk->qB);
-      sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true);
+      if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true);
+      else ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[2].stream));   // the gathered scalars are read on lane 3 too
       sorted_promise.set_value(sr);
     } catch (...) {
       sorted_promise.set_exception(std::current_exception());
       throw;
     }
-    msm_accum_g1(ctx, 2, sr, true, pB1, outB1, msm_ms[2]);
+    if (share_b) msm_accum_g1(ctx, 2, sr, true, pB1, outB1, msm_ms[2]);
+    else msm_run_g1(ctx, 2, pB1, zk->qB.scalars, zk->qB.cnt, outB1, msm_ms[2]);
   });
-  std::thread tB2 = guarded(2, [&] { msm_accum_g2(ctx, 3, sorted_ready.get(), false, pB2, outB2, msm_ms[3]); });
+  std::thread tB2 = guarded(2, [&] {
+    const MsmSorted* sr = sorted_ready.get();
+    if (share_b) msm_accum_g2(ctx, 3, sr, false, pB2, outB2, msm_ms[3]);
+    else msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
+  });
   std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
 
   std::exception_ptr main_err;

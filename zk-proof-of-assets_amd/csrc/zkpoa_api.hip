@@ -65,13 +65,18 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
     ctx->opt_msm_c = (int)value;
     return PROVER_OK;
   }
+  if (!strcmp(key, "msm_max_points")) {   // tests: force the chunked path at small sizes
+    if (value < 0) return PROVER_ERROR;
+    ctx->opt_msm_max_points = value;
+    return PROVER_OK;
+  }
   ctx->last_error = std::string("unknown option ") + key;
   return PROVER_ERROR;
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------
 static void check_n(uint64_t n) {
-  if (n > (1ull << 27)) throw HipError("msm: n too large (max 2^27 points per call)");
+  if (n > (1ull << 28)) throw HipError("msm: n too large (max 2^28 points per call)");
 }
 
 extern "C" int zkpoa_msm_g1_device(zkpoa_context* ctx, const void* d_bases, const void* d_scalars, uint64_t n,

@@ -20,6 +20,7 @@ struct zkpoa_context {
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float lane_ms[zkpoa::DeviceCtx::kLanes][2] = {};   // per-lane {whole MSM, accumulation kernel} of the last MSM
   int opt_msm_c = 0;
+  long opt_msm_max_points = 0;   // 0 = default (2^27): larger MSMs run in chunks
   hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
   hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
 };
