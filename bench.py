@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicated-chain", action="store_true",
                     help="prove workloads, N > 1: run the whole H-scalar chain on every rank instead of splitting it")
-    ap.add_argument("--inflight", type=int, default=3, help="MSMs kept in flight on separate HIP streams")
+    ap.add_argument("--inflight", type=int, default=6, help="MSMs kept in flight on separate HIP streams (1..6)")
     args = ap.parse_args()
 
     import numpy as np
