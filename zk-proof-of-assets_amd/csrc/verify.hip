@@ -5,7 +5,8 @@
 // as two C-ABI entry points over pairing.hpp. No GPU is needed or used: a verification is three
 // Miller loops and one final exponentiation (~15 ms on one core).
 #include "pairing.hpp"
-#include "zkpoa_internal.hpp"
+#include "../../include/zkpoa_prover.h"
+#include "host_curve.hpp"
 
 #include <stdexcept>
 #include <string>
@@ -14,6 +15,15 @@
 
 using namespace zkpoa;
 using namespace zkpoa::pairing;
+
+// (own copy: this translation unit is also linked on its own into zkpoa-verify / zkpoa-sanitize, which must not
+// pull in the HIP runtime -- loading it costs 0.1-0.3 s per process, ten times the verification itself)
+static void set_err(char* buf, unsigned long cap, const std::string& msg) {
+  if (!buf || cap == 0) return;
+  size_t k = msg.size() < cap - 1 ? msg.size() : cap - 1;
+  memcpy(buf, msg.data(), k);
+  buf[k] = 0;
+}
 
 namespace {
 
@@ -197,11 +207,10 @@ bool verify_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
     if (!parse_u256(pubj[i].scalar(), s) || !lt_modulus(s, HFrParams::P)) return false;
     vkx = g1_add_mul(vkx, vk.IC[i + 1], s);
   }
-  Fq12 f = miller_loop(pr.b, g1_neg(pr.a));
-  f = f * miller_loop(vk.beta2, vk.alpha1);
-  f = f * miller_loop(vk.gamma2, vkx);
-  f = f * miller_loop(vk.delta2, pr.c);
-  return final_exponentiation(f).is_one();
+  // e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1: one shared Miller accumulator, one final exponentiation
+  const G2 qs[4] = {pr.b, vk.beta2, vk.gamma2, vk.delta2};
+  const G1 ps[4] = {g1_neg(pr.a), vk.alpha1, vkx, pr.c};
+  return final_exponentiation(multi_miller_loop(qs, ps, 4)).is_one();
 }
 
 // ---- sanitizer: 43-bit x 6 limb arrays, Python json.dump formatting ----------------------------------------
