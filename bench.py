@@ -155,7 +155,7 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
                          "phase_ms": {kk: v / args.steps for kk, v in acc.items()}},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier(**args.barrier_kw)
         dist.destroy_process_group()
     circ.close()

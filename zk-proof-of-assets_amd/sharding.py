@@ -23,16 +23,25 @@ def shard_range(n, rank, world):
 
 
 def all_gather_bytes(payload, dist=None, device=None):
-    """All-gather a fixed-size byte string over the default process group; returns the list by rank."""
+    """All-gather a fixed-size byte string over the default process group; returns the list by rank.
+    On RCCL the ranks' payloads land in ONE tensor and come back with one device-to-host copy (the payload is a
+    few hundred bytes: the exchange is pure latency, so every extra synchronisation counts)."""
     import torch
     if dist is None or not dist.is_initialized():
         return [bytes(payload)]
+    world = dist.get_world_size()
     t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
     if device is not None:
         t = t.to(device)
-    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    if t.is_cuda:
+        out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        raw = out.cpu().numpy().tobytes()
+        n = t.numel()
+        return [raw[i * n:(i + 1) * n] for i in range(world)]
+    outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
-    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+    return [bytes(o.numpy().tobytes()) for o in outs]
 
 
 def combine_partials(group_sum, partials):
