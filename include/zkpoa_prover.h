@@ -39,7 +39,11 @@ extern "C" {
 /* zkey / wtns are complete file images. proof_buffer / public_buffer receive NUL-terminated
  * JSON text; *proof_size / *public_size are in: capacity, out: bytes needed incl. NUL (also
  * on PROVER_ERROR_SHORT_BUFFER). JSON style is rapidsnark's unless env ZKPOA_JSON=snarkjs.
- * r, s come from /dev/urandom unless env ZKPOA_R / ZKPOA_S (decimal) are set. */
+ * r, s come from /dev/urandom unless env ZKPOA_R / ZKPOA_S (decimal) are set.
+ * Self-check: like the reference, which verifies every proof right after proving it (scripts/g16_verify.sh:213-216),
+ * the first proof of every key is verified against the verification key the zkey itself carries (sections 2-3)
+ * before anything is returned; a failure is PROVER_ERROR with a message. Env ZKPOA_SELFCHECK=0 disables it,
+ * =all checks every proof (host only, ~7 ms). */
 int groth16_prover(const void* zkey_buffer, unsigned long zkey_size,
                    const void* wtns_buffer, unsigned long wtns_size,
                    char* proof_buffer, unsigned long* proof_size,
@@ -194,11 +198,22 @@ int zkpoa_groth16_verify(const char* vkey_json, const char* public_json, const c
                          char* error_msg, unsigned long error_msg_maxsize);
 int zkpoa_sanitize_proof(const char* vkey_json, const char* public_json, const char* proof_json,
                          char* buffer, unsigned long* size, char* error_msg, unsigned long error_msg_maxsize);
+/* The same verification on wire-format points, no JSON. vkey_points = alpha1(64) beta2(128) gamma2(128) delta2(128)
+ * then IC[(n_public+1) x 64] -- exactly the verification key a .zkey carries in sections 2 and 3 (what
+ * `snarkjs zkey export verificationkey`, scripts/g16_setup.sh:287-293, turns into <circuit>_vkey.json);
+ * proof_points as zkpoa_prove returns them; public_le = n_public x 32 B standard form. Same return codes.
+ * zkpoa_zkey_vkey copies that key out of a resident proving key (size protocol as groth16_prover; PROVER_ERROR
+ * when the handle has none: zkpoa_zkey_load_device keys). */
+int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned long vkey_size, const uint8_t proof_points[256],
+                                const uint8_t* public_le, unsigned long n_public, char* error_msg,
+                                unsigned long error_msg_maxsize);
+int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Timings (ms, HIP events on the stream that ran the kernels) of the last call on this context.
  * id: 0 = whole device part of last MSM, 1 = its bucket-accumulation kernel (dominant kernel),
- *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total.
+ *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total,
+ *     6 = last prove: self-check (host pairing check; 0 when it did not run).
  * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto); key "msm_max_points" sets the
  * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values). */
 float zkpoa_last_ms(const zkpoa_context* ctx, int id);

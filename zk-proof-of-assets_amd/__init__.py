@@ -39,7 +39,7 @@ EXPORTS = [
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
-    "zkpoa_groth16_verify", "zkpoa_sanitize_proof",
+    "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
 ]
 
 
@@ -127,6 +127,9 @@ def lib():
                                            ctypes.c_ulong]
         L.zkpoa_sanitize_proof.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ul_p,
                                            ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_groth16_verify_points.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_zkey_vkey.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ul_p]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
@@ -385,6 +388,17 @@ class ZKey:
         self._ctx._check(lib().zkpoa_zkey_set_shard_split(self._ctx._h, self._h, rank, world),
                          "zkpoa_zkey_set_shard_split")
 
+    def vkey_points(self):
+        """The verification key the zkey carries (sections 2-3): alpha1(64) beta2(128) gamma2(128) delta2(128) +
+        IC[(nPublic+1) x 64], wire format; None for keys assembled from device buffers."""
+        size = ctypes.c_ulong(0)
+        if lib().zkpoa_zkey_vkey(self._h, None, ctypes.byref(size)) != PROVER_ERROR_SHORT_BUFFER:
+            return None
+        buf = ctypes.create_string_buffer(size.value)
+        if lib().zkpoa_zkey_vkey(self._h, buf, ctypes.byref(size)) != PROVER_OK:
+            raise ZkpoaError("zkpoa_zkey_vkey failed")
+        return buf.raw
+
     def header(self):
         """alpha1(64) beta1(64) beta2(128) delta1(64) delta2(128), wire format."""
         out = ctypes.create_string_buffer(448)
@@ -438,6 +452,19 @@ def groth16_verify(vkey_json, public_json, proof_json):
     if rc == 0x10:
         return False
     raise ZkpoaError("zkpoa_groth16_verify: " + err.value.decode())
+
+
+def groth16_verify_points(vkey_points, proof_points, public_le):
+    """The same check on wire-format points (ZKey.vkey_points(), Context.prove() outputs); host only."""
+    err = ctypes.create_string_buffer(512)
+    pub = bytes(public_le)
+    rc = lib().zkpoa_groth16_verify_points(bytes(vkey_points), len(vkey_points), bytes(proof_points),
+                                           pub if pub else None, len(pub) // 32, err, 512)
+    if rc == PROVER_OK:
+        return True
+    if rc == 0x10:
+        return False
+    raise ZkpoaError("zkpoa_groth16_verify_points: " + err.value.decode())
 
 
 def sanitize_proof(vkey_json, public_json, proof_json):

@@ -108,6 +108,11 @@ struct zkpoa_zkey {
   uint64_t nCoefs = 0;
   Affine<HFq> alpha1, beta1, delta1;
   Affine<HFq2> beta2, delta2;
+  // Verification key carried by the zkey itself (section 2: alpha1, beta2, gamma2, delta2; section 3: IC), wire
+  // format alpha1(64) beta2(128) gamma2(128) delta2(128) IC[(nPublic+1) x 64]. Empty for keys assembled from
+  // device buffers (zkpoa_zkey_load_device has no gamma2 / IC). Used by the self-check of the first proof(s).
+  std::vector<uint8_t> vkey_points;
+  mutable uint64_t selfchecks_done = 0;
   void *dA = nullptr, *dB1 = nullptr, *dB2 = nullptr, *dC = nullptr, *dH = nullptr;
   uint32_t* d_row_ptr = nullptr;
   uint32_t* d_long = nullptr;   // constraints with more than kLongRow coefficients (abc.hip.h), n_long of them
@@ -345,10 +350,27 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
   if (zk->nPublic + 1 > zk->nVars) throw ProverError(PROVER_ERROR, "zkey nPublic >= nVars");
   zk->alpha1 = h_affine_from_bytes<HFq>(p); p += 64;
   zk->beta1 = h_affine_from_bytes<HFq>(p); p += 64;
+  const uint8_t* p_alpha1 = p - 128;
+  const uint8_t* p_beta2 = p;
   zk->beta2 = h_affine_from_bytes<HFq2>(p); p += 128;
-  p += 128;  // gamma2: verifier only
+  const uint8_t* p_gamma2 = p;
+  p += 128;  // gamma2: verifier only (kept for the self-check)
   zk->delta1 = h_affine_from_bytes<HFq>(p); p += 64;
+  const uint8_t* p_delta2 = p;
   zk->delta2 = h_affine_from_bytes<HFq2>(p);
+  // section 3 (IC) is optional for proving; with it the handle can verify its own proofs
+  {
+    auto it3 = secs.find(3);
+    if (it3 != secs.end() && it3->second.len == ((uint64_t)zk->nPublic + 1) * 64) {
+      zk->vkey_points.resize(448 + it3->second.len);
+      uint8_t* v = zk->vkey_points.data();
+      memcpy(v, p_alpha1, 64);
+      memcpy(v + 64, p_beta2, 128);
+      memcpy(v + 192, p_gamma2, 128);
+      memcpy(v + 320, p_delta2, 128);
+      memcpy(v + 448, it3->second.p, it3->second.len);
+    }
+  }
 
   const Section& s4 = need(secs, 4, "4 (coefficients)");
   if (s4.len < 4) throw ProverError(PROVER_ERROR, "zkey coefficient section too short");
@@ -721,6 +743,43 @@ void prove_core(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* r_le, c
   ctx->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// Self-check (ZKPOA_SELFCHECK): the reference verifies every proof right after proving it
+// (scripts/g16_verify.sh:213-216, full_workflow.sh:503-504); a zkey carries its own verification key, so the prover
+// can run the same pairing check before anything is written. "0" = never, unset / "1" = the first proof of every key
+// handle (a key whose conventions differ from SURVEY.md 8c fails on first contact, not downstream), "all" = every
+// proof. Host only (csrc/verify.hip, ~7 ms). Keys without section 3 / assembled from device buffers are skipped.
+int selfcheck_mode() {
+  const char* e = getenv("ZKPOA_SELFCHECK");
+  if (!e || !*e) return 1;
+  if (!strcmp(e, "0") || !strcmp(e, "off")) return 0;
+  if (!strcmp(e, "all") || !strcmp(e, "2")) return 2;
+  return 1;
+}
+
+void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_points[256], const uint8_t* public_le) {
+  ctx->ms[6] = 0;
+  const int mode = selfcheck_mode();
+  if (mode == 0 || zk->vkey_points.empty() || (mode == 1 && zk->selfchecks_done)) return;
+  auto t0 = std::chrono::steady_clock::now();
+  char msg[256] = {0};
+  int rc = zkpoa_groth16_verify_points(zk->vkey_points.data(), (unsigned long)zk->vkey_points.size(), proof_points,
+                                       public_le, zk->nPublic, msg, sizeof(msg));
+  ctx->ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (rc == PROVER_OK) {
+    zk->selfchecks_done++;
+    if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: self-check: proof verifies against the zkey's own verification key (%.1f ms)\n", ctx->ms[6]);
+    return;
+  }
+  if (rc == ZKPOA_VERIFY_INVALID_PROOF)
+    throw ProverError(PROVER_ERROR,
+                      "self-check failed: the proof does not verify against the verification key inside the zkey "
+                      "(sections 2-3). Either the witness does not satisfy the circuit, or this zkey does not follow the "
+                      "conventions the prover assumes: section 4 coefficients stored as coef*R^2 mod r; section 9 H points = "
+                      "Lagrange basis of the odd coset of the 2n-th roots (no division by Z); section 8 C points starting at "
+                      "wire nPublic+1; all points affine in Montgomery form. Set ZKPOA_SELFCHECK=0 to write the proof anyway.");
+  throw ProverError(PROVER_ERROR, std::string("self-check could not run: ") + msg);
+}
+
 void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
                 const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
                 uint64_t public_cap) {
@@ -734,6 +793,7 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
   prove_core(ctx, zk, r_le, s_le, proof_points);
   memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
+  selfcheck(ctx, zk, proof_points, w.values + 32);
 }
 
 // ---- JSON (byte formats pinned by the reference's committed fixtures) --------
@@ -870,9 +930,9 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
   if (getenv("ZKPOA_VERBOSE")) {
     fprintf(stderr,
             "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
-            "msm phase %.2f ms, prove %.2f ms\n",
+            "msm phase %.2f ms, prove %.2f ms, self-check %.2f ms\n",
             zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, cache_hit ? "cached," : "load", load_ms,
-            load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5]);
+            load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5], ctx->ms[6]);
   }
   return rc;
 }
@@ -1322,8 +1382,28 @@ extern "C" int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, co
                             hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     prove_core(ctx, zkey, r_le, s_le, proof_points);
+    if (!zkey->vkey_points.empty() && selfcheck_mode()) {
+      std::vector<uint8_t> pub((size_t)zkey->nPublic * 32 + 1);
+      if (zkey->nPublic)
+        ZK_HIP(hipMemcpy(pub.data(), reinterpret_cast<const char*>(zkey->d_witness) + 32, (size_t)zkey->nPublic * 32,
+                         hipMemcpyDeviceToHost));
+      selfcheck(ctx, zkey, proof_points, pub.data());
+    }
   }
   ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size) {
+  if (!zkey || !size) return PROVER_ERROR;
+  const unsigned long needed = (unsigned long)zkey->vkey_points.size();
+  if (needed == 0) return PROVER_ERROR;   // the handle carries no verification key
+  if (!buffer || *size < needed) {
+    *size = needed;
+    return PROVER_ERROR_SHORT_BUFFER;
+  }
+  memcpy(buffer, zkey->vkey_points.data(), needed);
+  *size = needed;
   return PROVER_OK;
 }
 

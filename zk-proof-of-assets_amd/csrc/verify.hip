@@ -48,13 +48,24 @@ struct JVal {
   }
 };
 
+constexpr int kJsonMaxDepth = 32;   // proof / vkey / public files nest 5 deep; deeper input is rejected, not recursed into
+
 struct JParser {
   const char* p;
+  int depth = 0;
   explicit JParser(const char* s) : p(s) {}
+  struct Nest {
+    int& d;
+    explicit Nest(int& depth) : d(depth) {
+      if (++d > kJsonMaxDepth) throw std::runtime_error("JSON: nesting too deep");
+    }
+    ~Nest() { --d; }
+  };
   void ws() {
     while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') p++;
   }
   JVal parse() {
+    Nest nest(depth);
     ws();
     JVal v;
     if (*p == '{') {
@@ -147,19 +158,24 @@ HFq fq_from_dec(const std::string& s) {
 }
 HFq2 fq2_from_json(const JVal& v) { return HFq2{fq_from_dec(v[0].scalar()), fq_from_dec(v[1].scalar())}; }
 
-// projective JSON forms: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]]; affine = (x/z, y/z) as in the reference's
-// sanitizer (scripts/sanitize_groth16_proof.py:44-59); z = 0 -> infinity
-G1 g1_from_json(const JVal& v) {
-  HFq x = fq_from_dec(v[0].scalar()), y = fq_from_dec(v[1].scalar()), z = fq_from_dec(v[2].scalar());
-  if (z.is_zero()) return {HFq::zero(), HFq::zero()};
-  HFq zi = z.inv();
-  return {x * zi, y * zi};
+// JSON point forms: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]]; z = 0 -> infinity, z = 1 -> affine. For any other
+// z the two consumers of these files differ and each entry point follows its own original: the reference's
+// sanitizer treats it as homogeneous projective, (x/z, y/z) (scripts/sanitize_groth16_proof.py:44-59), while
+// snarkjs' verifier (ffjavascript fromObject, g16_verify.sh:213-216) reads Jacobian coordinates, (x/z^2, y/z^3).
+enum class ZRule { Projective, Jacobian };
+template <class HF>
+Affine<HF> affine_from_xyz(const HF& x, const HF& y, const HF& z, ZRule rule) {
+  if (z.is_zero()) return {HF::zero(), HF::zero()};
+  HF zi = z.inv();
+  if (rule == ZRule::Projective) return {x * zi, y * zi};
+  HF zi2 = zi.sqr();
+  return {x * zi2, y * zi2 * zi};
 }
-G2 g2_from_json(const JVal& v) {
-  HFq2 x = fq2_from_json(v[0]), y = fq2_from_json(v[1]), z = fq2_from_json(v[2]);
-  if (z.is_zero()) return {HFq2::zero(), HFq2::zero()};
-  HFq2 zi = z.inv();
-  return {x * zi, y * zi};
+G1 g1_from_json(const JVal& v, ZRule rule) {
+  return affine_from_xyz<HFq>(fq_from_dec(v[0].scalar()), fq_from_dec(v[1].scalar()), fq_from_dec(v[2].scalar()), rule);
+}
+G2 g2_from_json(const JVal& v, ZRule rule) {
+  return affine_from_xyz<HFq2>(fq2_from_json(v[0]), fq2_from_json(v[1]), fq2_from_json(v[2]), rule);
 }
 G1 g1_neg(const G1& p) { return {p.x, p.y.neg()}; }
 
@@ -169,15 +185,24 @@ struct VKey {
   std::vector<G1> IC;
   size_t nPublic = 0;
 };
-VKey vkey_from_json(const JVal& v) {
+VKey vkey_from_json(const JVal& v, ZRule rule) {
   VKey k;
-  k.alpha1 = g1_from_json(v.at("vk_alpha_1"));
-  k.beta2 = g2_from_json(v.at("vk_beta_2"));
-  k.gamma2 = g2_from_json(v.at("vk_gamma_2"));
-  k.delta2 = g2_from_json(v.at("vk_delta_2"));
+  k.alpha1 = g1_from_json(v.at("vk_alpha_1"), rule);
+  k.beta2 = g2_from_json(v.at("vk_beta_2"), rule);
+  k.gamma2 = g2_from_json(v.at("vk_gamma_2"), rule);
+  k.delta2 = g2_from_json(v.at("vk_delta_2"), rule);
   const JVal& ic = v.at("IC");
-  for (const auto& p : ic.items) k.IC.push_back(g1_from_json(p));
-  k.nPublic = (size_t)std::stoull(v.at("nPublic").scalar());
+  if (ic.kind != JVal::ARR || ic.items.empty()) throw std::runtime_error("vkey: IC is empty");
+  for (const auto& p : ic.items) k.IC.push_back(g1_from_json(p, rule));
+  // nPublic: a plain non-negative decimal of at most 9 digits (std::stoull would wrap "-1" to 2^64 - 1)
+  const std::string& np = v.at("nPublic").scalar();
+  if (np.empty() || np.size() > 9) throw std::runtime_error("vkey: nPublic is not a small non-negative integer");
+  size_t n = 0;
+  for (char ch : np) {
+    if (ch < '0' || ch > '9') throw std::runtime_error("vkey: nPublic is not a small non-negative integer");
+    n = n * 10 + (size_t)(ch - '0');
+  }
+  k.nPublic = n;
   if (k.IC.size() != k.nPublic + 1) throw std::runtime_error("vkey: IC length does not match nPublic");
   return k;
 }
@@ -186,7 +211,9 @@ struct Proof {
   G1 a, c;
   G2 b;
 };
-Proof proof_from_json(const JVal& v) { return {g1_from_json(v.at("pi_a")), g1_from_json(v.at("pi_c")), g2_from_json(v.at("pi_b"))}; }
+Proof proof_from_json(const JVal& v, ZRule rule) {
+  return {g1_from_json(v.at("pi_a"), rule), g1_from_json(v.at("pi_c"), rule), g2_from_json(v.at("pi_b"), rule)};
+}
 
 G1 g1_add_mul(const G1& acc, const G1& p, const uint64_t k[4]) {
   XYZZ<HFq> r = XYZZ<HFq>::from_affine(acc);
@@ -196,21 +223,25 @@ G1 g1_add_mul(const G1& acc, const G1& p, const uint64_t k[4]) {
 
 // snarkjs groth16 verify: public inputs in the field, proof points on their curves,
 // e(-A, B) * e(alpha, beta) * e(vk_x, gamma) * e(C, delta) == 1
-bool verify_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
-  VKey vk = vkey_from_json(vkj);
-  Proof pr = proof_from_json(prj);
-  if (pubj.kind != JVal::ARR || pubj.items.size() != vk.nPublic) return false;
+// pub: nPublic standard-form scalars (4 x u64 each), already range-checked
+bool verify_core(const VKey& vk, const Proof& pr, const uint64_t* pub) {
   if (!g1_on_curve(pr.a) || !g1_on_curve(pr.c) || !g2_on_curve(pr.b)) return false;
   G1 vkx = vk.IC[0];
-  for (size_t i = 0; i < vk.nPublic; i++) {
-    uint64_t s[4];
-    if (!parse_u256(pubj[i].scalar(), s) || !lt_modulus(s, HFrParams::P)) return false;
-    vkx = g1_add_mul(vkx, vk.IC[i + 1], s);
-  }
+  for (size_t i = 0; i < vk.nPublic; i++) vkx = g1_add_mul(vkx, vk.IC[i + 1], pub + 4 * i);
   // e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1: one shared Miller accumulator, one final exponentiation
   const G2 qs[4] = {pr.b, vk.beta2, vk.gamma2, vk.delta2};
   const G1 ps[4] = {g1_neg(pr.a), vk.alpha1, vkx, pr.c};
   return final_exponentiation(multi_miller_loop(qs, ps, 4)).is_one();
+}
+
+bool verify_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
+  VKey vk = vkey_from_json(vkj, ZRule::Jacobian);
+  Proof pr = proof_from_json(prj, ZRule::Jacobian);
+  if (pubj.kind != JVal::ARR || pubj.items.size() != vk.nPublic) return false;
+  std::vector<uint64_t> pub(4 * vk.nPublic + 4);
+  for (size_t i = 0; i < vk.nPublic; i++)
+    if (!parse_u256(pubj[i].scalar(), &pub[4 * i]) || !lt_modulus(&pub[4 * i], HFrParams::P)) return false;
+  return verify_core(vk, pr, pub.data());
 }
 
 // ---- sanitizer: 43-bit x 6 limb arrays, Python json.dump formatting ----------------------------------------
@@ -233,8 +264,8 @@ std::string g2_limbs(const G2& p) { return "[" + fq2_limbs(p.x) + ", " + fq2_lim
 std::string g1_limbs(const G1& p) { return "[" + limbs43(p.x) + ", " + limbs43(p.y) + "]"; }
 
 std::string sanitize_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
-  VKey vk = vkey_from_json(vkj);
-  Proof pr = proof_from_json(prj);
+  VKey vk = vkey_from_json(vkj, ZRule::Projective);
+  Proof pr = proof_from_json(prj, ZRule::Projective);
   Fq12 nab = pairing::pairing(vk.beta2, g1_neg(vk.alpha1));   // pairing(beta, negalpha)
   HFq2 co[6];
   nab.fq2_coeffs(co);
@@ -249,7 +280,6 @@ std::string sanitize_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
     uint64_t s[4];
     if (!parse_u256(pubj[i].scalar(), s)) throw std::runtime_error("public input is not a decimal integer");
     // int(pubInput): re-emit the canonical decimal (strips leading zeros like Python's int())
-    HFr t{{s[0], s[1], s[2], s[3]}};
     std::string dec;
     {  // decimal of a raw 256-bit integer
       uint64_t v[4] = {s[0], s[1], s[2], s[3]};
@@ -265,7 +295,6 @@ std::string sanitize_impl(const JVal& vkj, const JVal& pubj, const JVal& prj) {
       }
       dec = rev.empty() ? "0" : std::string(rev.rbegin(), rev.rend());
     }
-    (void)t;
     o += dec + (i + 1 < pubj.items.size() ? ", " : "");
   }
   o += "]}";
@@ -279,6 +308,35 @@ extern "C" int zkpoa_groth16_verify(const char* vkey_json, const char* public_js
   try {
     JVal vk = parse_json(vkey_json), pub = parse_json(public_json), pr = parse_json(proof_json);
     return verify_impl(vk, pub, pr) ? PROVER_OK : ZKPOA_VERIFY_INVALID_PROOF;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+}
+
+// Same check on wire-format points (what a zkey and the prover hold): no JSON, no decimal conversion.
+extern "C" int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned long vkey_size,
+                                           const uint8_t proof_points[256], const uint8_t* public_le,
+                                           unsigned long n_public, char* error_msg, unsigned long error_msg_maxsize) {
+  try {
+    if (!vkey_points || !proof_points || (n_public && !public_le)) throw std::runtime_error("null argument");
+    if (vkey_size != 448 + ((unsigned long)n_public + 1) * 64)
+      throw std::runtime_error("vkey_points: expected alpha1(64) beta2(128) gamma2(128) delta2(128) + (nPublic+1) IC points");
+    VKey vk;
+    vk.alpha1 = h_affine_from_bytes<HFq>(vkey_points);
+    vk.beta2 = h_affine_from_bytes<HFq2>(vkey_points + 64);
+    vk.gamma2 = h_affine_from_bytes<HFq2>(vkey_points + 192);
+    vk.delta2 = h_affine_from_bytes<HFq2>(vkey_points + 320);
+    vk.nPublic = n_public;
+    for (unsigned long i = 0; i <= n_public; i++) vk.IC.push_back(h_affine_from_bytes<HFq>(vkey_points + 448 + 64 * i));
+    Proof pr{h_affine_from_bytes<HFq>(proof_points), h_affine_from_bytes<HFq>(proof_points + 192),
+             h_affine_from_bytes<HFq2>(proof_points + 64)};
+    std::vector<uint64_t> pub(4 * (size_t)n_public + 4);
+    for (unsigned long i = 0; i < n_public; i++) {
+      memcpy(&pub[4 * i], public_le + 32 * i, 32);
+      if (!lt_modulus(&pub[4 * i], HFrParams::P)) return ZKPOA_VERIFY_INVALID_PROOF;
+    }
+    return verify_core(vk, pr, pub.data()) ? PROVER_OK : ZKPOA_VERIFY_INVALID_PROOF;
   } catch (const std::exception& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     return PROVER_ERROR;
