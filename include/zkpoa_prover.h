@@ -141,6 +141,11 @@ int zkpoa_split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d
 int zkpoa_split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_received, void* d_exchange);
 int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_received);
 
+/* The H-MSM scalars of the LAST prove on this key handle (joinABC output, groth16_prove.js; domain x 32 B standard
+ * form, or domain / world for a split shard: odd-coset indices i = rank mod world), copied to the host. Parity
+ * tests use it to check pi_c at sizes where no CPU transform is affordable (oracle quotient identity). */
+int zkpoa_zkey_read_h_scalars(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* out, unsigned long capacity);
+
 /* proof_points / public -> JSON text. style 0 = rapidsnark bytes, 1 = snarkjs bytes
  * (SURVEY.md 8a row a11). Size protocol as groth16_prover. */
 int zkpoa_proof_to_json(const uint8_t proof_points[256], int style, char* buffer, unsigned long* size);

@@ -12,6 +12,7 @@
  *   orc_msm_g1/g2   = G1/G2.multiExpAffine (here: textbook Pippenger, unsigned c-bit windows,
  *                     threaded by window like rapidsnark's ParallelMultiexp)
  *   orc_prove       = groth16Prove (five MSMs + randomised assembly)
+ *   orc_quotient_check = an NTT-free polynomial-identity test of a complete H-scalar vector (full-size pi_c checks)
  * Pinning: this file is checked against oracle/py (big-int Python), which is itself pinned by the
  * reference's committed proof/vkey fixtures through the pairing verifier; the (zkey, wtns) -> proof
  * map has no golden vector in the reference ("prover parity unpinned" beyond that chain).
@@ -372,6 +373,127 @@ int orc_h_scalars(const void* coeffs, uint64_t coeffs_size, const void* witness,
   for (uint64_t i = 0; i < n; i++) { fe t; fe_mul(&FR, &t, &A[i], &B[i]); fe_sub(&FR, &t, &t, &C[i]); fe_from_mont(&FR, &o[i], &t); }
   free(A);
   return 0;
+}
+
+/* ---- quotient identity: an NTT-free O(n) check of a COMPLETE H-scalar vector ---------------------------
+ * groth16_prove.js hands the H MSM the scalars P[i] = (A*B - C)(x_i) on the coset x_i = g*w^i (g = inc =
+ * w_{2n}; SURVEY.md 8c "H basis"), where A, B, C (degree < n) interpolate buildABC1's A_T, B_T, C_T = A_T o B_T
+ * on the domain {w^c}. A*B - C vanishes on the domain by construction, so A*B - C = Hq * (x^n - 1) with
+ * deg Hq <= n - 2 and P[i] = Hq(x_i) * (g^n - 1). Hence, for ANY point z,
+ *       A(z) * B(z) - C(z)  ==  Hq(z) * (z^n - 1),
+ * with A(z), B(z), C(z) by the barycentric formula over the domain and Hq(z) by the barycentric formula
+ * over the coset from the n values P[i] / (g^n - 1). For a random z a wrong vector passes with probability
+ * <= 2n / r (Schwartz-Zippel): one field equation checks all n scalars, at full size, with no transform in
+ * common with the path under test (buildABC + 4n-element barycentric sums, ~12 n multiplications, threaded).
+ * Returns 0 = identity holds, 1 = it does not, other = malformed input. */
+typedef struct {
+  const coef_rec* recs; uint32_t ncoef; const fe* w; uint64_t nvars; uint64_t n; unsigned k;
+  const fe* P; fe z, g; fe* A; fe* B; uint64_t lo, hi; int bad;
+  fe sa, sb, sc, sh;
+} qc_job;
+#define QC_BLK 1024
+/* sum_j f[j] * x_j / (z - x_j) over j in [lo, hi), x_j = x0 * w^j: batch inversion per block */
+static int qc_bary(const fe* z, const fe* x0, const fe* wn, uint64_t lo, uint64_t hi, const fe* const* f, int nf,
+                   int std_form, fe* out) {
+  fe xs[QC_BLK], pre[QC_BLK], x, wl; uint64_t e[4] = {lo, 0, 0, 0};
+  fe_pow(&FR, &wl, wn, e); fe_mul(&FR, &x, x0, &wl);
+  for (int q = 0; q < nf; q++) memset(&out[q], 0, sizeof(fe));
+  for (uint64_t s = lo; s < hi; s += QC_BLK) {
+    uint64_t cnt = hi - s < QC_BLK ? hi - s : QC_BLK;
+    fe acc = FR.one;
+    for (uint64_t j = 0; j < cnt; j++) {
+      xs[j] = x; fe d; fe_sub(&FR, &d, z, &x);
+      if (fe_is_zero(&d)) return 3;
+      pre[j] = acc; fe_mul(&FR, &acc, &acc, &d);
+      fe_mul(&FR, &x, &x, wn);
+    }
+    fe inv; fe_inv(&FR, &inv, &acc);
+    for (uint64_t j = cnt; j-- > 0;) {
+      fe d, wgt; fe_sub(&FR, &d, z, &xs[j]);
+      fe_mul(&FR, &wgt, &inv, &pre[j]);            /* 1 / (z - x_j) */
+      fe_mul(&FR, &inv, &inv, &d);
+      fe_mul(&FR, &wgt, &wgt, &xs[j]);
+      for (int q = 0; q < nf; q++) {
+        fe v = f[q][s + j], t;
+        if (std_form) fe_to_mont(&FR, &v, &v);
+        fe_mul(&FR, &t, &v, &wgt); fe_add(&FR, &out[q], &out[q], &t);
+      }
+    }
+  }
+  return 0;
+}
+static void* qc_worker(void* arg) {
+  qc_job* j = (qc_job*)arg;
+  /* buildABC1 for the constraints [lo, hi): every thread walks the whole list and keeps its own rows */
+  for (uint32_t i = 0; i < j->ncoef; i++) {
+    coef_rec r; memcpy(&r, &j->recs[i], 44);
+    if (r.m > 1 || r.c >= j->n || r.s >= j->nvars) { j->bad = 2; return 0; }
+    if (r.c < j->lo || r.c >= j->hi) continue;
+    fe v, p; memcpy(&v, r.val, 32);
+    fe_mul(&FR, &p, &v, &j->w[r.s]);
+    fe* dst = (r.m ? j->B : j->A) + r.c;
+    fe_add(&FR, dst, dst, &p);
+  }
+  fe* C = (fe*)malloc((size_t)(j->hi - j->lo) * sizeof(fe));
+  for (uint64_t c = j->lo; c < j->hi; c++) fe_mul(&FR, &C[c - j->lo], &j->A[c], &j->B[c]);
+  fe wn; fr_root(&wn, j->k);
+  const fe* fs[3] = {j->A, j->B, C - j->lo};
+  fe out[3];
+  int rc = qc_bary(&j->z, &FR.one, &wn, j->lo, j->hi, fs, 3, 0, out);
+  j->sa = out[0]; j->sb = out[1]; j->sc = out[2];
+  free(C);
+  const fe* fh[1] = {j->P};
+  if (!rc) rc = qc_bary(&j->z, &j->g, &wn, j->lo, j->hi, fh, 1, 1, &j->sh);
+  if (rc) j->bad = rc;
+  return 0;
+}
+/* coeffs: payload of zkey section 4; witness: nvars x 32 B standard form; h_scalars: 2^k x 32 B standard form
+ * (what the H MSM consumes); z_le: the evaluation point, standard form, < r. */
+int orc_quotient_check(const void* coeffs, uint64_t coeffs_size, const void* witness, uint64_t nvars, unsigned k,
+                       const void* h_scalars, const uint8_t* z_le, int nthreads) {
+  const uint8_t* cb = (const uint8_t*)coeffs;
+  uint32_t ncoef; memcpy(&ncoef, cb, 4);
+  if (coeffs_size != 4 + (uint64_t)ncoef * 44 || k > 28) return 4;
+  uint64_t n = 1ull << k;
+  if (nthreads < 1) nthreads = 1;
+  if ((uint64_t)nthreads > n) nthreads = (int)n;
+  fe* A = (fe*)calloc(2 * n, sizeof(fe)); fe* B = A + n;
+  fe z, g, t; memcpy(&t, z_le, 32); fe_to_mont(&FR, &z, &t);
+  if (k == 28) fe_from_u64(&FR, &g, 25); else fr_root(&g, k + 1);
+  qc_job* jobs = (qc_job*)calloc((size_t)nthreads, sizeof(qc_job));
+  pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  for (int i = 0; i < nthreads; i++) {
+    jobs[i] = (qc_job){(const coef_rec*)(cb + 4), ncoef, (const fe*)witness, nvars, n, k, (const fe*)h_scalars, z, g,
+                       A, B, n * (uint64_t)i / (uint64_t)nthreads, n * (uint64_t)(i + 1) / (uint64_t)nthreads, 0};
+    if (i) pthread_create(&th[i], 0, qc_worker, &jobs[i]);
+  }
+  qc_worker(&jobs[0]);
+  for (int i = 1; i < nthreads; i++) pthread_join(th[i], 0);
+  int rc = 0;
+  fe sa, sb, sc, sh; memset(&sa, 0, 32); sb = sc = sh = sa;
+  for (int i = 0; i < nthreads; i++) {
+    if (jobs[i].bad) rc = jobs[i].bad;
+    fe_add(&FR, &sa, &sa, &jobs[i].sa); fe_add(&FR, &sb, &sb, &jobs[i].sb);
+    fe_add(&FR, &sc, &sc, &jobs[i].sc); fe_add(&FR, &sh, &sh, &jobs[i].sh);
+  }
+  free(A); free(jobs); free(th);
+  if (rc) return rc;
+  /* f(z) = (z^n - 1) / n * S_f;   Hq(z) = (z^n - g^n) / (n g^n (g^n - 1)) * S_h */
+  uint64_t en[4] = {n, 0, 0, 0};
+  fe zn, gn, zn1, ninv, lhs, rhs, az, bz, cz, hz, den;
+  fe_pow(&FR, &zn, &z, en); fe_pow(&FR, &gn, &g, en);
+  fe_sub(&FR, &zn1, &zn, &FR.one);
+  fe_from_u64(&FR, &ninv, n); fe_inv(&FR, &ninv, &ninv);
+  fe_mul(&FR, &t, &zn1, &ninv);
+  fe_mul(&FR, &az, &t, &sa); fe_mul(&FR, &bz, &t, &sb); fe_mul(&FR, &cz, &t, &sc);
+  fe_sub(&FR, &den, &gn, &FR.one); fe_mul(&FR, &den, &den, &gn);
+  if (fe_is_zero(&den)) return 5;
+  fe_inv(&FR, &den, &den);
+  fe_sub(&FR, &t, &zn, &gn); fe_mul(&FR, &t, &t, &ninv); fe_mul(&FR, &t, &t, &den);
+  fe_mul(&FR, &hz, &t, &sh);
+  fe_mul(&FR, &lhs, &az, &bz); fe_sub(&FR, &lhs, &lhs, &cz);
+  fe_mul(&FR, &rhs, &hz, &zn1);
+  return fe_eq(&lhs, &rhs) ? 0 : 1;
 }
 
 /* ---- full prove (groth16_prove.js), container parsing included ------------------------------------ */

@@ -23,6 +23,7 @@ def lib():
         L.orc_fixed_base_g2.argtypes = [vp, u64, vp, ci]
         L.orc_ntt.argtypes = [vp, ctypes.c_uint, ci]
         L.orc_h_scalars.argtypes = [vp, u64, vp, u64, ctypes.c_uint, vp]
+        L.orc_quotient_check.argtypes = [vp, u64, vp, u64, ctypes.c_uint, vp, ctypes.c_char_p, ci]
         L.orc_prove.argtypes = [vp, u64, vp, u64, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ci]
         L.orc_field_op.argtypes = [ci, ci, vp, vp, vp, u64]
         L.orc_group_add.argtypes = [ci, vp, vp, vp, u64]
@@ -84,6 +85,30 @@ def h_scalars(coeffs_section, witness, n_vars, k):
     if rc:
         raise ValueError("orc_h_scalars rc=%d" % rc)
     return out.raw
+
+
+def _ptr(b):
+    """bytes or a C-contiguous numpy array -> (address, keepalive), without copying."""
+    if isinstance(b, (bytes, bytearray)):
+        if isinstance(b, bytes):
+            return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p), b
+        arr = (ctypes.c_char * len(b)).from_buffer(b)
+        return ctypes.cast(arr, ctypes.c_void_p), arr
+    return ctypes.c_void_p(b.ctypes.data), b          # numpy
+
+
+def quotient_check(coeffs_section, witness, n_vars, k, h_scalars, z, nthreads=1):
+    """True iff the 2^k standard-form H scalars satisfy A(z) B(z) - C(z) == Hq(z) (z^n - 1) at the point z
+    (A, B, C from buildABC1 over coeffs_section + witness): a Schwartz-Zippel check of the COMPLETE vector with
+    no NTT (oracle/c/zkpoa_oracle.c: orc_quotient_check). Buffers: bytes or numpy arrays (not copied)."""
+    pc, kc = _ptr(coeffs_section)
+    pw, kw = _ptr(witness)
+    ph, kh = _ptr(h_scalars)
+    size = len(coeffs_section) if isinstance(coeffs_section, (bytes, bytearray)) else coeffs_section.nbytes
+    rc = lib().orc_quotient_check(pc, size, pw, n_vars, k, ph, int(z).to_bytes(32, "little"), nthreads)
+    if rc not in (0, 1):
+        raise ValueError("orc_quotient_check rc=%d" % rc)
+    return rc == 0
 
 
 def prove(zkey, wtns, r=0, s=0, nthreads=1, n_public=None):

@@ -145,3 +145,39 @@ def test_c_fixed_base_and_mid_size_circuit():
     pts, pub = co.prove(zk, wt, r_, s_, nthreads=4)
     proof = {"pi_a": g16.g1_from_bytes(pts, 0), "pi_b": g16.g2_from_bytes(pts, 64), "pi_c": g16.g1_from_bytes(pts, 192)}
     assert g16.verify(vk, [rd(pub, i) for i in range(nPublic)], g16.proof_to_obj(proof))
+
+
+# ---- quotient identity (full-size pi_c checks): pinned on the golden H scalars ----------------------------------
+@pytest.mark.parametrize("tag,k", [("n8", 3), ("n128", 7)])
+def test_quotient_identity_on_golden_h_scalars(tag, k):
+    """orc_quotient_check accepts the golden H scalars (made by the big-int Python oracle through iNTT / coset /
+    NTT) at random points, on 1 and 3 threads, and rejects a one-bit change and the scalars of another witness."""
+    from conftest import golden_case
+    g = golden_case(tag)
+    z = g["circuit.zkey"]
+    secs = g16.read_binfile(z, "zkey", 2)
+    p4, l4 = secs[4][0]
+    coeffs = z[p4:p4 + l4]
+    _, wit = g16.read_wtns(g["witness.wtns"])
+    wb = b"".join(w.to_bytes(32, "little") for w in wit)
+    h = g["h_scalars.bin"]
+    rng = random.Random(1)
+    R = bn.R
+    for nt in (1, 3):
+        assert co.quotient_check(coeffs, wb, len(wit), k, h, rng.randrange(R), nt)
+    bad = bytearray(h)
+    bad[33] ^= 1
+    assert not co.quotient_check(coeffs, wb, len(wit), k, bytes(bad), rng.randrange(R), 2)
+    # an unsatisfying witness still has a quotient (C_T = A_T o B_T by construction): its own scalars pass, the
+    # other witness's do not
+    wit2 = list(wit)
+    wit2[3] = (wit2[3] + 5) % R
+    wb2 = b"".join(w.to_bytes(32, "little") for w in wit2)
+    h2 = co.h_scalars(coeffs, wb2, len(wit), k)
+    assert h2 != h
+    assert co.quotient_check(coeffs, wb2, len(wit), k, h2, rng.randrange(R), 2)
+    assert not co.quotient_check(coeffs, wb2, len(wit), k, h, rng.randrange(R), 2)
+    # numpy buffers are taken without copying
+    import numpy as np
+    assert co.quotient_check(np.frombuffer(coeffs, dtype=np.uint8), np.frombuffer(wb, dtype=np.uint64).reshape(-1, 4),
+                             len(wit), k, np.frombuffer(h, dtype=np.uint64).reshape(-1, 4), rng.randrange(R), 2)

@@ -168,7 +168,7 @@ def test_selfcheck_catches_broken_conventions(ctx, zk, what, monkeypatch):
         z = _patch(z, 8, 0, z[p8 + 64:p8 + l8] + z[p8:p8 + 64])
     else:                                       # a witness that does not satisfy the circuit
         _, wit = g16.read_wtns(w)
-        wit[-1] = (wit[-1] + 1) % R
+        wit[3] = (wit[3] + 1) % R
         w = g16.write_wtns(wit)
     key = ctx.load_zkey(z)
     try:

@@ -40,6 +40,7 @@ EXPORTS = [
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
+    "zkpoa_zkey_read_h_scalars",
 ]
 
 
@@ -130,6 +131,7 @@ def lib():
         L.zkpoa_groth16_verify_points.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_zkey_vkey.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ul_p]
+        L.zkpoa_zkey_read_h_scalars.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.groth16_prover.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong,
@@ -339,6 +341,14 @@ class Context:
         parts = ctypes.create_string_buffer(384)
         self._check(lib().zkpoa_prove_partials_device(self._h, zkey._h, d_witness, parts), "zkpoa_prove_partials_device")
         return parts.raw
+
+    def read_h_scalars(self, zkey, count):
+        """H-MSM scalars of the last prove on `zkey` (count x 32 B standard form) as a numpy uint64 [count, 4]."""
+        import numpy as np
+        out = np.empty((count, 4), dtype=np.uint64)
+        self._check(lib().zkpoa_zkey_read_h_scalars(self._h, zkey._h, out.ctypes.data, out.nbytes),
+                    "zkpoa_zkey_read_h_scalars")
+        return out
 
     def prove_device(self, zkey, d_witness, r=None, s=None):
         """Prove with the witness already in HBM -> (proof_points[256], public bytes)."""

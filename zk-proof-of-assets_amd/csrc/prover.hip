@@ -1394,6 +1394,20 @@ extern "C" int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, co
   return PROVER_OK;
 }
 
+extern "C" int zkpoa_zkey_read_h_scalars(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* out, unsigned long capacity) {
+  if (!ctx || !zkey || !out) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    const uint64_t cnt = zkey->split_world > 1 ? (uint64_t)zkey->domain >> zkey->split_log : zkey->domain;
+    if (capacity < cnt * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "h-scalar buffer too small");
+    if (!zkey->d_abc) throw ProverError(PROVER_ERROR, "no H scalars on this handle");
+    ZK_HIP(hipDeviceSynchronize());
+    ZK_HIP(hipMemcpy(out, zkey->d_abc, cnt * 32, hipMemcpyDeviceToHost));
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
 extern "C" int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size) {
   if (!zkey || !size) return PROVER_ERROR;
   const unsigned long needed = (unsigned long)zkey->vkey_points.size();

@@ -96,7 +96,10 @@ class SyntheticCircuit:
         r2 = (1 << 512) % R_MOD                           # coefficient 1 is stored as 1 * R^2
         val = torch.tensor([(r2 >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=torch.int64).to(torch.int32)
         n_coef = 3 * n_cons + n_public + 1
-        recs = torch.empty((n_coef, 11), dtype=torch.int32)
+        # host image of zkey section 4 (u32 count + 44-byte records) in one buffer; `recs` is a view of the records
+        self._sec4 = np.empty(4 + n_coef * 44, dtype=np.uint8)
+        self._sec4[:4] = np.frombuffer(int(n_coef).to_bytes(4, "little"), dtype=np.uint8)
+        recs = torch.from_numpy(self._sec4[4:].view(np.int32).reshape(n_coef, 11))
         recs[:, 3:] = val
         for t, mat in enumerate((0, 0, 1)):
             blk = recs[t * n_cons:(t + 1) * n_cons]
@@ -142,9 +145,17 @@ class SyntheticCircuit:
                                         self.d_recs.data_ptr(), n_coef, hp)
         self._G1, self._G2 = G1, G2
 
+    def coeff_section(self):
+        """Payload of zkey section 4 (u32 count + records) as a numpy uint8 array (no copy)."""
+        return self._sec4
+
     def coeff_section_bytes(self):
-        """Payload of zkey section 4 (u32 count + records) for the host-buffer entry points."""
-        return int(self.n_coef).to_bytes(4, "little") + self.recs_host.numpy().tobytes()
+        """Same, as bytes (a copy), for the host-buffer entry points."""
+        return self._sec4.tobytes()
+
+    def h_scalars(self):
+        """H-MSM scalars of the last prove on this key, read back from HBM: numpy uint64 [n, 4] (standard form)."""
+        return self.ctx.read_h_scalars(self.key, self.n)
 
     def witness_bytes(self):
         return self.w_limbs.tobytes()
@@ -153,7 +164,9 @@ class SyntheticCircuit:
         return self.ctx.prove_device(self.key, self.d_witness.data_ptr(), r, s)
 
     def expected_dlogs(self, r, s, h_scalars_bytes=None):
-        """(a, b, c) with c = None when the H scalars are not supplied."""
+        """(a, b, c) with c = None when the H scalars are not supplied (bytes or a numpy uint64 [n, 4] array).
+        The caller supplies H scalars it has validated independently of this package (the tests and bench.py do:
+        a CPU restatement of the chain at test sizes, a polynomial-identity check at full size)."""
         import numpy as np
         sums = {}
         for x, present in (("A", self.in_a), ("B", self.in_b)):
@@ -169,7 +182,8 @@ class SyntheticCircuit:
             wc = self.w_limbs[self.n_public + 1:]
             c0, c1 = dlog_sums(wc)
             csum = (self.par["C"][0] * c0 + self.par["C"][1] * c1) % R_MOD
-            P = np.frombuffer(h_scalars_bytes, dtype=np.uint64).reshape(-1, 4)
+            P = (h_scalars_bytes if isinstance(h_scalars_bytes, np.ndarray)
+                 else np.frombuffer(h_scalars_bytes, dtype=np.uint64).reshape(-1, 4))
             h0, h1 = dlog_sums(P)
             hsum = (self.par["H"][0] * h0 + self.par["H"][1] * h1) % R_MOD
             c = (csum + hsum + s * a + r * b - r * s % R_MOD * de) % R_MOD
