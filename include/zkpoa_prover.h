@@ -220,7 +220,8 @@ int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size
  *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total,
  *     6 = last prove: self-check (host pairing check; 0 when it did not run).
  * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto); key "msm_max_points" sets the
- * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values). */
+ * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values);
+ * key "prove_serial" = 1 runs the stages of a prove one after the other (solo device times for the roofline). */
 float zkpoa_last_ms(const zkpoa_context* ctx, int id);
 int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value);
 

@@ -189,7 +189,7 @@ static void q_inv(fe* r, const fe* a) { fe_inv(&FQ, r, a); }
 DEFINE_CURVE(g1, fe, q_add, q_sub, q_mul, fe_is_zero, fe_eq, q_inv, FQ_ONE_INIT)
 DEFINE_CURVE(g2, fe2, f2_add, f2_sub, f2_mul, f2_is_zero, f2_eq, f2_inv, FQ2_ONE_INIT)
 
-/* ---- Pippenger MSM: unsigned c-bit windows, one thread per window stripe ------------------------- */
+/* ---- Pippenger MSM: unsigned c-bit windows, threaded over (window, point-chunk) tasks ----------------- */
 static unsigned scalar_window(const uint64_t* k, unsigned bit, unsigned c) {
   unsigned limb = bit >> 6, off = bit & 63;
   if (limb > 3) return 0;
@@ -206,22 +206,28 @@ static unsigned pick_c(uint64_t n) {
   return best;
 }
 
+/* Work is cut into (window, point-chunk) tasks handed out through an atomic counter, so every host core is busy
+ * whatever the window count (rapidsnark's ParallelMultiexp likewise splits the points across threads). */
 #define DEFINE_MSM(PFX, AFFSZ)                                                                             \
-  typedef struct { const PFX##_aff* bases; const uint64_t* scalars; uint64_t n; unsigned c, W, w0, wstep;  \
-                   PFX##_jac* win; } PFX##_job;                                                            \
+  typedef struct { const PFX##_aff* bases; const uint64_t* scalars; uint64_t n; unsigned c, W, nchunks;    \
+                   volatile unsigned* next; PFX##_jac* part; } PFX##_job;                                  \
   static void* PFX##_worker(void* arg) {                                                                   \
     PFX##_job* j = (PFX##_job*)arg;                                                                        \
     size_t nb = (size_t)1 << j->c;                                                                         \
     PFX##_jac* buckets = (PFX##_jac*)malloc(nb * sizeof(PFX##_jac));                                      \
-    for (unsigned w = j->w0; w < j->W; w += j->wstep) {                                                    \
+    for (;;) {                                                                                             \
+      unsigned t = __atomic_fetch_add(j->next, 1u, __ATOMIC_RELAXED);                                      \
+      if (t >= j->W * j->nchunks) break;                                                                   \
+      unsigned w = t / j->nchunks, ch = t % j->nchunks;                                                    \
+      uint64_t lo = j->n * ch / j->nchunks, hi = j->n * (ch + 1) / j->nchunks;                             \
       memset(buckets, 0, nb * sizeof(PFX##_jac));                                                          \
-      for (uint64_t i = 0; i < j->n; i++) {                                                                \
+      for (uint64_t i = lo; i < hi; i++) {                                                                 \
         unsigned d = scalar_window(j->scalars + 4 * i, w * j->c, j->c);                                    \
         if (d) PFX##_madd(&buckets[d], &buckets[d], &j->bases[i]);                                         \
       }                                                                                                    \
       PFX##_jac run, sum; PFX##_set_inf(&run); PFX##_set_inf(&sum);                                        \
       for (size_t b = nb - 1; b >= 1; b--) { PFX##_add(&run, &run, &buckets[b]); PFX##_add(&sum, &sum, &run); } \
-      j->win[w] = sum;                                                                                     \
+      j->part[t] = sum;                                                                                    \
     }                                                                                                      \
     free(buckets);                                                                                         \
     return 0;                                                                                              \
@@ -230,24 +236,25 @@ static unsigned pick_c(uint64_t n) {
   int orc_msm_##PFX(const void* bases, const void* scalars, uint64_t n, void* out, int nthreads) {         \
     unsigned c = pick_c(n ? n : 1), W = (254 + c - 1) / c;                                                 \
     if (nthreads < 1) nthreads = 1;                                                                        \
-    if ((unsigned)nthreads > W) nthreads = (int)W;                                                         \
-    PFX##_jac* win = (PFX##_jac*)calloc(W, sizeof(PFX##_jac));                                            \
-    PFX##_job* jobs = (PFX##_job*)calloc((size_t)nthreads, sizeof(PFX##_job));                            \
+    /* ~2 tasks per thread; a chunk keeps >= 4 * 2^c points so the per-task bucket reduction stays small */\
+    unsigned nchunks = (2u * (unsigned)nthreads + W - 1) / W;                                              \
+    while (nchunks > 1 && n / nchunks < ((uint64_t)4 << c)) nchunks--;                                     \
+    if (nthreads == 1) nchunks = 1;                                                                        \
+    if ((unsigned)nthreads > W * nchunks) nthreads = (int)(W * nchunks);                                   \
+    PFX##_jac* part = (PFX##_jac*)calloc((size_t)W * nchunks, sizeof(PFX##_jac));                         \
+    PFX##_job job = {(const PFX##_aff*)bases, (const uint64_t*)scalars, n, c, W, nchunks, 0, part};        \
+    volatile unsigned next = 0; job.next = &next;                                                          \
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));                               \
-    for (int t = 0; t < nthreads; t++) {                                                                   \
-      jobs[t] = (PFX##_job){(const PFX##_aff*)bases, (const uint64_t*)scalars, n, c, W, (unsigned)t,       \
-                            (unsigned)nthreads, win};                                                      \
-      if (t) pthread_create(&th[t], 0, PFX##_worker, &jobs[t]);                                            \
-    }                                                                                                      \
-    PFX##_worker(&jobs[0]);                                                                                \
+    for (int t = 1; t < nthreads; t++) pthread_create(&th[t], 0, PFX##_worker, &job);                      \
+    PFX##_worker(&job);                                                                                    \
     for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);                                             \
     PFX##_jac acc; PFX##_set_inf(&acc);                                                                    \
     for (int w = (int)W - 1; w >= 0; w--) {                                                                \
       for (unsigned k = 0; k < c; k++) PFX##_dbl(&acc, &acc);                                              \
-      PFX##_add(&acc, &acc, &win[w]);                                                                      \
+      for (unsigned ch = 0; ch < nchunks; ch++) PFX##_add(&acc, &acc, &part[(size_t)w * nchunks + ch]);    \
     }                                                                                                      \
     PFX##_aff r; PFX##_to_aff(&r, &acc); memcpy(out, &r, AFFSZ);                                           \
-    free(win); free(jobs); free(th);                                                                       \
+    free(part); free(th);                                                                                  \
     return 0;                                                                                              \
   }
 DEFINE_MSM(g1, 64)

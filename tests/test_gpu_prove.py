@@ -623,9 +623,11 @@ def test_prove_edge_shapes(ctx, zk, nVars, nPublic, nCons):
     assert zk.groth16_verify(json.dumps(vk), zk.public_to_json(pub), zk.proof_to_json(pts))
 
 
-def test_prove_degenerate_witness(ctx, zk):
+def test_prove_degenerate_witness(ctx, zk, monkeypatch):
     """w = (1, 0, 0, ...): every witness MSM collapses to (at most) one base; H scalars are all zero. The
-    result must still equal the oracle's (proofs of a non-satisfying witness simply do not verify)."""
+    result must still equal the oracle's (proofs of a non-satisfying witness simply do not verify, so the
+    prover's self-check is switched off here)."""
+    monkeypatch.setenv("ZKPOA_SELFCHECK", "0")
     rng = random.Random(5)
     zkey, vk, w = _setup_small(rng, 50, 2, 40)
     w0 = [1] + [0] * 49

@@ -611,19 +611,26 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
                          ctx->dev.lanes[lane_id].stream, (const uint4*)zk->d_witness, (const uint32_t*)q.wire + q.lo,
                          q.cnt, (uint4*)q.scalars);
   };
+  // opt_prove_serial (measurement only): every stage runs alone, one after the other, so the per-stage device times
+  // are solo times and their sum / the overlapped wall time says how much the five lanes gain (bench.py).
+  const bool serial = ctx->opt_prove_serial != 0;
   std::thread tA = guarded(0, [&] {
     gather(1, zk->qA);
     msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1]);
   });
+  if (serial) tA.join();
   // (a B query beyond the 32-bit entry index of one sort cannot share it: two chunked MSMs instead)
   const uint64_t sort_limit = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
   const bool share_b = zk->qB.cnt <= sort_limit;
+  float sort_b_ms = 0;   // the shared sort of the B query (host clock: the call returns with its stream synchronised)
   std::thread tB1 = guarded(1, [&] {
     MsmSorted* sr = nullptr;
     try {
       gather(2, zk->qB);
+      auto ts0 = std::chrono::steady_clock::now();
       if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true);
       else ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[2].stream));   // the gathered scalars are read on lane 3 too
+      sort_b_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - ts0).count();
       sorted_promise.set_value(sr);
     } catch (...) {
       sorted_promise.set_exception(std::current_exception());
@@ -631,13 +638,17 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
     }
     if (share_b) msm_accum_g1(ctx, 2, sr, true, pB1, outB1, msm_ms[2]);
     else msm_run_g1(ctx, 2, pB1, zk->qB.scalars, zk->qB.cnt, outB1, msm_ms[2]);
+    if (share_b) msm_ms[2][0] += sort_b_ms;
   });
+  if (serial) tB1.join();
   std::thread tB2 = guarded(2, [&] {
     const MsmSorted* sr = sorted_ready.get();
     if (share_b) msm_accum_g2(ctx, 3, sr, false, pB2, outB2, msm_ms[3]);
     else msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
   });
+  if (serial) tB2.join();
   std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
+  if (serial) tC.join();
 
   std::exception_ptr main_err;
   try {
@@ -657,10 +668,12 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   } catch (...) {
     main_err = std::current_exception();
   }
-  tA.join();
-  tB1.join();
-  tB2.join();
-  tC.join();
+  if (!serial) {
+    tA.join();
+    tB1.join();
+    tB2.join();
+    tC.join();
+  }
   try {
     msm_sorted_free(const_cast<MsmSorted*>(sorted_ready.get()));
   } catch (...) {

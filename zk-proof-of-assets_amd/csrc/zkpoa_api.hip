@@ -70,6 +70,10 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
     ctx->opt_msm_max_points = value;
     return PROVER_OK;
   }
+  if (!strcmp(key, "prove_serial")) {     // measurement: no overlap between the stages of a prove
+    ctx->opt_prove_serial = value != 0;
+    return PROVER_OK;
+  }
   ctx->last_error = std::string("unknown option ") + key;
   return PROVER_ERROR;
 }

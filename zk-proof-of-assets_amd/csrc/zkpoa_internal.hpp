@@ -21,6 +21,7 @@ struct zkpoa_context {
   float lane_ms[zkpoa::DeviceCtx::kLanes][2] = {};   // per-lane {whole MSM, accumulation kernel} of the last MSM
   int opt_msm_c = 0;
   long opt_msm_max_points = 0;   // 0 = default (2^27): larger MSMs run in chunks
+  int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
   hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
   hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
 };
