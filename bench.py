@@ -6,9 +6,13 @@ points / scalars, inputs resident in HBM. One "step" = one complete MSM over the
 slice (weak scaling: with N ranks the job is one N*2^20-point MSM whose per-rank partial points are
 all-gathered over RCCL and summed on every rank -- SURVEY.md 8e).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm_g1_2p20|msm_g1_2pXX|prove_2pXX]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm_g1_2p20|msm_g1_2pXX|prove_2pXX] [--no-also]
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0. BASELINE.json's metric is "Groth16 proofs/sec + G1-MSM pts/s at 2^20 / 2^26", so
+with N = 1 and the default workload the same line carries, under "also", the other shapes of that metric measured
+in the same process: the 2^26 MSM, the 2^20 MSM in fixed-base form, and full proves at the layer_one(2 sigs)
+2^21 shape and the synthetic layer_one(128 sigs) 2^26 shape -- each with its own step count, roofline object and
+correctness check (pi_c included). `value` is always the headline workload alone.
 """
 import argparse
 import json
@@ -21,26 +25,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 VALU_PEAK_GADDS = 12.1      # XYZZ mixed additions/s: register-only loop of the same addition on one MI355X at its best
                             # occupancy (tools/microbench.hip: 11.6 at 3 waves/SIMD, 12.1 at 4)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
+DTYPE = "u32x8 (254-bit modular integer)"
+
+
+class BenchError(Exception):
+    """A correctness check of something that was timed failed."""
 
 
 def pmc_traffic(workload, kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated on this access pattern:
-    profiles/r01_pmc_hbm_traffic.json). None when this workload has not been profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-        for name, v in prof["workloads"].get(workload, {}).items():
-            if kernel_substr in name:
-                return v["bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    profiles/rNN_pmc_hbm_traffic.json, newest round first). None when this workload has not been profiled."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % rnd)
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            for name, v in prof["workloads"].get(workload, {}).items():
+                if kernel_substr in name:
+                    return v["bytes_per_launch"], "profiles/%s_pmc_hbm_traffic.json" % rnd
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def np_scalars(n, seed):
@@ -51,16 +62,20 @@ def np_scalars(n, seed):
     return limbs
 
 
-def dlog_expected(limbs, a, b, i0):
-    import numpy as np
-    n = limbs.shape[0]
-    idx = np.arange(i0, i0 + n, dtype=object)
-    s0 = s1 = 0
-    for j in range(4):
-        col = limbs[:, j].astype(object)
-        s0 += int(col.sum()) << (64 * j)
-        s1 += int((col * idx).sum()) << (64 * j)
-    return (a * s0 + b * s1) % R_MOD
+def host_cores():
+    """Cores this process may run on (the GPU box gives a job a share of the host, not all of it)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def classic_window(n):
+    """Window width the library's cost model picks for a classic n-point MSM (csrc/msm.hip.h msm_make_plan)."""
+    def cost(c):
+        w = (254 + c - 1) // c
+        return w * n * (1.0 + 0.06 * ((c - 1 + 7) // 8)) + 8.0 * w * (1 << (c - 1))
+    return min(range(4, 23), key=cost)
 
 
 # circuit shapes of the reference's own test runs (SURVEY.md 8 "Sizes at BASELINE.json configs")
@@ -72,32 +87,232 @@ PROVE_SHAPES = {
 }
 
 
-def bench_prove(args, zk, dist, rank, world, local_rank, dev):
-    """Full Groth16 prove against a key + witness resident in HBM. N>1: the proof's five MSMs are sharded
-    over the ranks (BASELINE.json configs[3..4]); the H-scalar chain is replicated."""
+class Env:
+    """Everything a leg needs: the package, one device context, the process group."""
+
+    def __init__(self, args, zk, dist, rank, world, local_rank, dev):
+        self.args, self.zk, self.dist = args, zk, dist
+        self.rank, self.world, self.local_rank, self.dev = rank, world, local_rank, dev
+        self.ctx = zk.Context(local_rank)
+        self.force_dist = os.environ.get("ZKPOA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with one rank
+        self.multi = world > 1 or self.force_dist
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.multi:
+            self.dist.barrier(**self.args.barrier_kw)
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        if not self.multi:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.args.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def agree(self, ok, what):
+        """Every rank takes the same exit path: a failed local check fails the job everywhere (no rank is left
+        waiting in a collective)."""
+        import torch
+        if self.multi:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.args.cdev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        if not ok:
+            raise BenchError(what)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def msm_leg(env, logn, steps, warmup, inflight, fixed_base=False, cpu_baseline=False):
+    """G1 MSM over 2^logn points per rank, `inflight` MSMs kept in flight on separate lanes. -> line dict."""
+    import numpy as np
     import torch
-    from zkpoa_amd.synthetic import SyntheticCircuit
-    k = int(args.workload[len("prove_2p"):])
-    m, n_pub, what = PROVE_SHAPES[k]
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     from zkpoa_amd import sharding
-    ctx = zk.Context(local_rank)
+    from zkpoa_amd.synthetic import dlog_sums
+    zk, ctx, dist, args = env.zk, env.ctx, env.dist, env.args
+    n_local = 1 << logn
+    if logn > 27:
+        raise SystemExit("msm workload limited to 2^27 points per GPU")
+
+    # ---- synthetic inputs, resident in HBM: bases (a + i*b)*G with known discrete logs, uniform scalars
+    seeds = random.Random(0x5EED0001)
+    a, b = seeds.randrange(R_MOD), seeds.randrange(R_MOD)
+    i0 = env.rank * n_local
+    d_bases = torch.empty(n_local * 64, dtype=torch.uint8, device=env.dev)
+    ctx.gen_bases_g1_device(a, b, i0, n_local, d_bases.data_ptr())
+    limbs = np_scalars(n_local, 0x5EED0002 + env.rank)
+    d_scalars = torch.from_numpy(limbs.view(np.uint8).reshape(-1)).to(env.dev)
+    table = None
+    if fixed_base:
+        table = ctx.msm_table(1, d_bases.data_ptr(), n_local, int(os.environ.get("ZKPOA_MSM_C") or 0))
+
+    # `inflight` MSMs are kept in flight, each on its own lane (HIP stream + workspace) driven by its own
+    # host thread: the sort / bucket-reduction / read-back / host-Horner phases of one MSM are small or
+    # latency-bound and overlap with the accumulation kernel of the next (the prover does the same with
+    # its five MSMs). Collectives stay on the main thread, in step order.
+    inflight = max(1, min(inflight, 6))
+    pool = ThreadPoolExecutor(inflight)
+
+    def msm_on(lane):
+        if table is not None:
+            part = ctx.msm_table_run(table, d_scalars.data_ptr(), lane)
+        else:
+            part = ctx.msm_g1_device_lane(lane, d_bases.data_ptr(), d_scalars.data_ptr(), n_local)
+        return part, ctx.last_ms_lane(lane, 1), ctx.last_ms_lane(lane, 0)
+
+    def combine(part):
+        if not env.multi:
+            return part
+        return sharding.combine_partials(zk.g1_sum, sharding.all_gather_bytes(part, dist, args.cdev))
+
+    def run(count):
+        """-> (last result, sum of accumulate-kernel ms, sum of whole-MSM device ms)"""
+        q = deque(pool.submit(msm_on, i % inflight) for i in range(min(inflight, count)))
+        res, k_ms, d_ms = None, 0.0, 0.0
+        for i in range(count):
+            part, k1, k0 = q.popleft().result()
+            if i + inflight < count:
+                q.append(pool.submit(msm_on, i % inflight))      # lane i % inflight is free again: refill it
+            res = combine(part)                                  # ... before the (blocking) collective
+            k_ms += k1     # HIP events on the MSM's own stream, inside the library
+            d_ms += k0
+        return res, k_ms, d_ms
+
+    try:
+        run(max(warmup, inflight))      # also sizes every lane's workspace outside the timed region
+        env.sync()
+        t0 = time.perf_counter()
+        result, kernel_ms, msm_dev_ms = run(steps)
+        env.sync()
+        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+        # the dominant kernel ALONE (nothing else in flight on the chip): three more MSMs, one at a time, after the
+        # timed region; the roofline fractions below use this duration, never an overlapped one
+        solo_k, solo_d = 0.0, 0.0
+        for _ in range(3):
+            _, k1, k0 = msm_on(0)
+            solo_k += k1 / 3
+            solo_d += k0 / 3
+    finally:
+        pool.shutdown()
+
+    # ---- correctness of what was timed (outside the timed region): known-dlog check
+    s0, s1 = dlog_sums(limbs, i0)
+    d_loc = (a * s0 + b * s1) % R_MOD
+    if env.multi:
+        parts = [None] * env.world
+        dist.all_gather_object(parts, d_loc)
+        d_all = sum(parts) % R_MOD
+    else:
+        d_all = d_loc
+    Gm = ((1 << 256) % Q_MOD).to_bytes(32, "little") + ((2 << 256) % Q_MOD).to_bytes(32, "little")
+    env.agree(result == zk.g1_mul(Gm, d_all), "MSM result failed the known-dlog check")
+
+    line = None
+    if env.rank == 0:
+        if table is not None:
+            _, c_win, windows, table_bytes = table.info()
+        else:
+            c_win = int(os.environ.get("ZKPOA_MSM_C") or classic_window(n_local))
+            windows, table_bytes = (254 + c_win - 1) // c_win, 0
+        adds = n_local * windows
+        achieved = G1_MSM_BYTES_PER_POINT * n_local / (solo_k * 1e-3) / 1e9
+        gadds = adds / (solo_k * 1e-3) / 1e9
+        wl = "msm_g1_2p%d" % logn
+        traffic, tsrc = pmc_traffic(wl + ("_fixed_base" if fixed_base else ""), "msm_accum0_kernel")
+        line = {
+            "metric": "G1-MSM throughput", "value": n_local * env.world * steps / elapsed, "unit": "pts/s",
+            "n_gpus": env.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE,
+            "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo collectives; not a measurement)"
+                                   if args.rehearse else ""),
+            "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d points per GPU, uniform 252-bit scalars, bases "
+                                   "(a+i*b)*G resident in HBM%s" % (logn, " (BASELINE.json configs[1])" if logn == 20 else
+                                                                   " (BASELINE.json configs[4] MSM part)" if logn == 26 else ""),
+                       "points_per_gpu": n_local, "sharding": "index ranges, all-gather of partial points",
+                       "msms_in_flight": inflight,
+                       "form": ("fixed-base: 2^(c*j)*P_i precomputed once per base array (%.2f GB table), all windows "
+                                "in one bucket set" % (table_bytes / 1e9)) if fixed_base else
+                               "classic: arbitrary bases, nothing precomputed",
+                       "checked": "known discrete log of the result (O(n) field arithmetic)"},
+            "roofline": {"bound": "hbm", "kernel": "msm_accum0_kernel<Fq> (bucket accumulation)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "kernel_ms": solo_k, "kernel_ms_overlapped": kernel_ms / steps,
+                         "msm_device_ms_solo": solo_d, "msm_device_ms_overlapped": msm_dev_ms / steps,
+                         "valu": {"unit": "G mixed additions/s", "achieved": gadds, "peak": VALU_PEAK_GADDS,
+                                  "frac": gadds / VALU_PEAK_GADDS, "additions_per_launch": adds, "window_bits": c_win,
+                                  "windows": windows},
+                         "note": "achieved = 96 B/point x points per launch / kernel_ms, kernel_ms = the accumulation "
+                                 "kernel alone on the chip (HIP events on its stream, 3 launches after the timed "
+                                 "region; kernel_ms <= ms_per_step). The kernel is integer-VALU-bound (v_mad_u64_u32), "
+                                 "not HBM-bound: `valu` is the bound that binds (DESIGN.md section 4)"},
+        }
+        if cpu_baseline:
+            line["cpu_baseline"] = cpu_msm_baseline(env, d_bases, limbs, logn)
+    if table is not None:
+        table.close()
+    del d_bases, d_scalars
+    torch.cuda.empty_cache()
+    return line
+
+
+def cpu_msm_baseline(env, d_bases, limbs, logn):
+    """The C oracle's Pippenger (oracle/c, -O3, threaded over (window, point-chunk) tasks) on ALL host cores, on a
+    bounded sample of the same workload; checked against the GPU on that sample."""
+    from oracle import c_oracle as co
+    cores = host_cores()
+    sample_log = min(logn, 20)
+    ns = 1 << sample_log
+    hb = bytes(d_bases[:ns * 64].cpu().numpy())
+    hs = limbs[:ns].tobytes()
+    reps = 3
+    tc = time.perf_counter()
+    for _ in range(reps):
+        ref = co.msm_g1(hb, hs, ns, cores)
+    tcpu = (time.perf_counter() - tc) / reps
+    import torch
+    d_s = torch.frombuffer(bytearray(hs), dtype=torch.uint8).to(env.dev)
+    chk = env.ctx.msm_g1_device(d_bases.data_ptr(), d_s.data_ptr(), ns)
+    if chk != ref:
+        raise BenchError("GPU and CPU-oracle MSM disagree on the baseline sample")
+    return {"value": ns / tcpu, "unit": "pts/s", "cores": cores, "nproc": cores, "kind": "port",
+            "sample": "first 2^%d points of the same workload, mean of %d MSMs; C oracle (oracle/c: plain-C "
+                      "Pippenger, unsigned windows, Jacobian, u128 Montgomery, gcc -O3 -march=x86-64-v3 -madx), "
+                      "%d threads = every host core of the GPU box; a stand-in for rapidsnark (absent here), "
+                      "not a tuned CPU prover" % (sample_log, reps, cores),
+            "seconds": tcpu * reps}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def prove_leg(env, k, steps, warmup, precompute=True):
+    """Full Groth16 prove against a key + witness resident in HBM. N>1: the proof's five MSMs are sharded
+    over the ranks (BASELINE.json configs[3..4]); the H-scalar chain is split or replicated."""
+    import torch
+    from zkpoa_amd import sharding
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    zk, ctx, dist, args = env.zk, env.ctx, env.dist, env.args
+    m, n_pub, what = PROVE_SHAPES[k]
+    world, rank = env.world, env.rank
     # N > 1: ONE proof sharded over the N GPUs (strong scaling): same circuit on every rank, each rank
     # owns index range rank/N of the five MSMs; partial points are all-gathered over RCCL and summed.
     circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True)
     header = circ.key.header()
     split = world > 1 and not args.replicated_chain and sharding.split_chain_supported(world, 1 << k)
+    xbufs = None
+    table_bytes = 0
     if split:
         # the H-scalar chain is split over the ranks too: rows c = rank (mod N), two all-to-alls per polynomial
         circ.key.set_shard_split(rank, world)
-        xbufs = sharding.exchange_buffers(1 << k, world, dev)
+        xbufs = sharding.exchange_buffers(1 << k, world, env.dev)
     elif world > 1:
         circ.key.set_shard(rank, world)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(**args.barrier_kw)
-        torch.cuda.synchronize()
+    elif precompute:
+        table_bytes = circ.key.precompute()      # resident key: fixed-base tables, once, outside the timed region
 
     def one_proof():
         if world == 1:
@@ -108,60 +323,105 @@ def bench_prove(args, zk, dist, rank, world, local_rank, dev):
         return sharding.sharded_prove(lambda: ctx.prove_partials_device(circ.key, circ.d_witness.data_ptr()),
                                       header, zk.sum_partials, zk.prove_assemble, 0, 0, dist, args.cdev)
 
-    for _ in range(args.warmup):
-        one_proof()
-    sync()
-    t0 = time.perf_counter()
-    acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
     names = ("H", "A", "B1", "B2", "C")
-    acc.update({"msm_%s" % x: 0.0 for x in names})
-    for i in range(args.steps):
-        pts = one_proof()
-        acc["h_chain"] += ctx.last_ms(3)
-        acc["msm_phase"] += ctx.last_ms(4)
-        acc["prove"] += ctx.last_ms(5)
-        acc["h_msm_accum"] += ctx.last_ms(1)
-        for lane, x in enumerate(names):                 # device time of each MSM on its own lane (they overlap)
-            acc["msm_%s" % x] += ctx.last_ms_lane(lane, 0)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=args.cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if not circ.check(pts, 0, 0):
-        raise SystemExit("bench.py: proof failed the known-dlog check (pi_a / pi_b)")
+    try:
+        for _ in range(warmup):
+            one_proof()
+        env.sync()
+        t0 = time.perf_counter()
+        acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
+        acc.update({"msm_%s" % x: 0.0 for x in names})
+        for i in range(steps):
+            pts = one_proof()
+            acc["h_chain"] += ctx.last_ms(3)
+            acc["msm_phase"] += ctx.last_ms(4)
+            acc["prove"] += ctx.last_ms(5)
+            acc["h_msm_accum"] += ctx.last_ms(1)
+            for lane, x in enumerate(names):                 # device time of each MSM on its own lane (they overlap)
+                acc["msm_%s" % x] += ctx.last_ms_lane(lane, 0)
+        env.sync()
+        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+
+        # ---- every stage ALONE (nothing else on the chip): two proofs with the stages serialised. Their sum against
+        # the overlapped wall time says how much of a proof is arithmetic and how much is scheduling.
+        solo = None
+        if world == 1:
+            ctx.set_option("prove_serial", 1)
+            try:
+                solo = {"h_chain": 0.0}
+                solo.update({"msm_%s" % x: 0.0 for x in names})
+                for _ in range(2):
+                    if circ.prove(0, 0)[0] != pts:
+                        raise BenchError("serialised prove differs from the overlapped one")
+                    solo["h_chain"] += ctx.last_ms(3) / 2
+                    for lane, x in enumerate(names):
+                        solo["msm_%s" % x] += ctx.last_ms_lane(lane, 0) / 2
+            finally:
+                ctx.set_option("prove_serial", 0)
+
+        # ---- correctness of what was timed: pi_a, pi_b AND pi_c against the known-dlog expectation. The H scalars
+        # the GPU produced are read back and validated independently of any transform by the oracle's quotient
+        # identity A(z)B(z) - C(z) = H(z)(z^n - 1) at a random point (oracle/c: orc_quotient_check).
+        ok, checked = True, "pi_a, pi_b by known discrete log"
+        if world == 1:
+            from oracle import c_oracle as co
+            P = circ.h_scalars()
+            zpt = random.Random(0xC0FFEE + k).randrange(R_MOD)
+            threads = min(32, host_cores())
+            tq = time.perf_counter()
+            ok = co.quotient_check(circ.coeff_section(), circ.w_limbs, m, k, P, zpt, threads)
+            tq = time.perf_counter() - tq
+            ok = ok and circ.check(pts, 0, 0, P)
+            checked = ("pi_a, pi_b, pi_c by known discrete log; the 2^%d H scalars by the oracle's quotient identity at a "
+                       "random point (%.1f s on %d host threads)" % (k, tq, threads))
+        else:
+            ok = circ.check(pts, 0, 0)
+        env.agree(ok, "proof failed the known-dlog / quotient-identity check")
+    except BaseException:
+        circ.close()
+        raise
+
+    line = None
     if rank == 0:
         n = 1 << k
         ncoef = circ.n_coef
         # SURVEY.md 8d full-prove formula
         alg = 96 * (3 * m - n_pub - 1) + 160 * m + 96 * n + 6 * 64 * n + 76 * ncoef + 96 * n + 128 * n
-        sec = elapsed / args.steps
+        sec = elapsed / steps
+        roof = {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
+                "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes": alg,
+                "phase_ms_overlapped": {kk: v / steps for kk, v in acc.items()}}
+        if solo is not None:
+            tot = sum(solo.values())
+            roof["valu"] = {"stage_ms_solo": solo, "sum_solo_ms": tot, "wall_ms": sec * 1e3, "ratio": tot / (sec * 1e3),
+                            "note": "every stage timed alone on the chip (prove_serial) vs the overlapped proof: "
+                                    "ratio > 1 = the lanes overlap that much work; the stages are integer-VALU-bound "
+                                    "(MSMs) or VALU + HBM (NTT chain), see DESIGN.md section 4"}
         line = {
-            "metric": "Groth16 proofs/sec", "value": args.steps / elapsed, "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "metric": "Groth16 proofs/sec", "value": steps / elapsed, "unit": "proofs/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32x8 (254-bit modular integer)", "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo "
-                                                                              "collectives; not a measurement)" if args.rehearse else ""),
+            "dtype": DTYPE, "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo "
+                                                   "collectives; not a measurement)" if args.rehearse else ""),
             "config": {"workload": "full Groth16 prove, domain 2^%d, %d wires, %d public (%s); key and witness "
                                    "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
-                       "n_coefs": ncoef, "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
+                       "n_coefs": ncoef,
+                       "fixed_base_tables_GB": table_bytes / 1e9,
+                       "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
                                        "points; H-scalar chain %s" % (world, "split (four-step NTTs, 2 all-to-alls per "
-                                       "polynomial)" if split else "replicated")) if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
-                         "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes": alg,
-                         "phase_ms": {kk: v / args.steps for kk, v in acc.items()}},
+                                       "polynomial)" if split else "replicated")) if world > 1 else "single GPU",
+                       "checked": checked},
+            "roofline": roof,
         }
-        print(json.dumps(line), flush=True)
-    if dist.is_initialized():
-        dist.barrier(**args.barrier_kw)
-        dist.destroy_process_group()
     circ.close()
-    ctx.close()
+    del circ, xbufs
+    torch.cuda.empty_cache()
+    return line
 
 
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,17 +429,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="msm_g1_2p20")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="headline workload only (no 'also' legs)")
+    ap.add_argument("--fixed-base", action="store_true", help="msm workloads: fixed-base form (precomputed table)")
+    ap.add_argument("--no-precompute", action="store_true", help="prove workloads: no fixed-base tables")
     ap.add_argument("--replicated-chain", action="store_true",
                     help="prove workloads, N > 1: run the whole H-scalar chain on every rank instead of splitting it")
     ap.add_argument("--inflight", type=int, default=6, help="MSMs kept in flight on separate HIP streams (1..6)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
     zk = load_package()
-    from zkpoa_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +460,7 @@ def main():
     args.cdev = torch.device("cpu") if rehearse else dev           # where collective payloads live
     args.barrier_kw = {} if rehearse else {"device_ids": [local_rank]}
     args.rehearse = rehearse
-    force_dist = os.environ.get("ZKPOA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with one rank
+    force_dist = os.environ.get("ZKPOA_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -208,155 +469,55 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.workload.startswith("prove_2p"):
-        return bench_prove(args, zk, dist, rank, world, local_rank, dev)
-    if args.workload.startswith("msm_g1_2p"):
-        logn = int(args.workload[len("msm_g1_2p"):])
-    else:
-        raise SystemExit("unknown workload " + args.workload)
-    n_local = 1 << logn
-    ctx = zk.Context(local_rank)
-    if os.environ.get("ZKPOA_MSM_C"):        # experiments only: force the Pippenger window width
-        ctx.set_option("msm_c", int(os.environ["ZKPOA_MSM_C"]))
-    if logn > 27:
-        raise SystemExit("msm workload limited to 2^27 points per GPU")
-
-    # ---- synthetic inputs, resident in HBM: bases (a + i*b)*G with known discrete logs, uniform scalars
-    seeds = random.Random(0x5EED0001)
-    a, b = seeds.randrange(R_MOD), seeds.randrange(R_MOD)
-    i0 = rank * n_local
-    d_bases = torch.empty(n_local * 64, dtype=torch.uint8, device=dev)
-    ctx.gen_bases_g1_device(a, b, i0, n_local, d_bases.data_ptr())
-    limbs = np_scalars(n_local, 0x5EED0002 + rank)
-    d_scalars = torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).to(dev)
-
-    # `inflight` MSMs are kept in flight, each on its own lane (HIP stream + workspace) driven by its own
-    # host thread: the sort / bucket-reduction / read-back / host-Horner phases of one MSM are small or
-    # latency-bound and overlap with the accumulation kernel of the next (the prover does the same with
-    # its five MSMs). Collectives stay on the main thread, in step order.
-    from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
-    inflight = max(1, min(args.inflight, 6))
-    pool = ThreadPoolExecutor(inflight)
-
-    def msm_on(lane):
-        part = ctx.msm_g1_device_lane(lane, d_bases.data_ptr(), d_scalars.data_ptr(), n_local)
-        return part, ctx.last_ms_lane(lane, 1), ctx.last_ms_lane(lane, 0)
-
-    def combine(part):
-        if world == 1 and not force_dist:
-            return part
-        return sharding.combine_partials(zk.g1_sum, sharding.all_gather_bytes(part, dist, args.cdev))
-
-    def run(steps):
-        """-> (last result, sum of accumulate-kernel ms, sum of whole-MSM device ms)"""
-        q = deque(pool.submit(msm_on, i % inflight) for i in range(min(inflight, steps)))
-        res, k_ms, d_ms = None, 0.0, 0.0
-        for i in range(steps):
-            part, k1, k0 = q.popleft().result()
-            if i + inflight < steps:
-                q.append(pool.submit(msm_on, i % inflight))      # lane i % inflight is free again: refill it
-            res = combine(part)                                  # ... before the (blocking) collective
-            k_ms += k1     # HIP events on the MSM's own stream, inside the library
-            d_ms += k0
-        return res, k_ms, d_ms
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1 or force_dist:
-            dist.barrier(**args.barrier_kw)
-        torch.cuda.synchronize()
-
-    run(max(args.warmup, inflight))      # also sizes every lane's workspace outside the timed region
-    sync()
-    t0 = time.perf_counter()
-    result, kernel_ms, msm_dev_ms = run(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    pool.shutdown()
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=args.cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- correctness of what was timed (outside the timed region): known-dlog check
-    d_loc = dlog_expected(limbs, a, b, i0)
-    if world > 1 or force_dist:
-        parts = [None] * world
-        dist.all_gather_object(parts, d_loc)
-        d_all = sum(parts) % R_MOD
-    else:
-        d_all = d_loc
-    G = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
-    one_m = (1 << 256) % 21888242871839275222246405745257275088696311157297823662689037894645226208583
-    two_m = (2 << 256) % 21888242871839275222246405745257275088696311157297823662689037894645226208583
-    Gm = one_m.to_bytes(32, "little") + two_m.to_bytes(32, "little")
-    expected = zk.g1_mul(Gm, d_all)
-    if result != expected:
-        raise SystemExit("bench.py: MSM result failed the known-dlog check")
-
-    if rank == 0:
-        pts_total = n_local * world * args.steps
-        k_ms = kernel_ms / args.steps
-        achieved = G1_MSM_BYTES_PER_POINT * n_local / (k_ms * 1e-3) / 1e9
-        # the bound that actually binds: one XYZZ mixed addition per (point, window) entry; window width from the
-        # library's cost model (csrc/msm.hip.h msm_make_plan), ceiling = register-only loop of the same addition
-        # measured on this chip (tools/microbench2.hip, DESIGN.md section 4)
-        c_win = int(os.environ.get("ZKPOA_MSM_C") or
-                    min(range(4, 23), key=lambda c: ((254 + c - 1) // c) * (n_local + 8.0 * (1 << (c - 1)))))
-        adds = n_local * ((254 + c_win - 1) // c_win)
-        gadds = adds / (k_ms * 1e-3) / 1e9
-        line = {
-            "metric": "G1-MSM throughput", "value": pts_total / elapsed, "unit": "pts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x8 (254-bit modular integer)",
-            "data": "synthetic" + (" (REHEARSAL: ranks share a GPU, gloo collectives; not a measurement)"
-                                   if args.rehearse else ""),
-            "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d points per GPU, uniform 252-bit scalars, "
-                                   "bases (a+i*b)*G resident in HBM (BASELINE.json configs[1])" % logn,
-                       "points_per_gpu": n_local, "sharding": "index ranges, all-gather of partial points",
-                       "msms_in_flight": inflight},
-            "roofline": {"bound": "hbm", "kernel": "msm_accum0_kernel<Fq> (bucket accumulation)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, "msm_accum0_kernel"),
-                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE, bytes per launch; each base is re-read once per window)",
-                         "kernel_ms": k_ms, "msm_device_ms": msm_dev_ms / args.steps,
-                         "valu": {"unit": "G mixed additions/s", "achieved": gadds, "peak": VALU_PEAK_GADDS,
-                                  "frac": gadds / VALU_PEAK_GADDS, "additions_per_launch": adds, "window_bits": c_win,
-                                  "note": "kernel_ms is per launch with %d MSMs in flight, so launches overlap "
-                                          "other kernels; --inflight 1 gives the kernel alone" % inflight},
-                         "note": "algorithmic bytes = 96 B/point x points per launch; the kernel is "
-                                 "integer-VALU-bound (v_mad_u64_u32), not HBM-bound: see DESIGN.md"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import c_oracle as co
-            cores = os.cpu_count() or 1
-            sample_log = min(logn, 20)      # ~10-20 s of CPU work spread over the host cores
-            ns = 1 << sample_log
-            hb = bytes(d_bases[:ns * 64].cpu().numpy())
-            hs = limbs[:ns].tobytes()
-            windows = co.msm_windows(ns)     # the C oracle threads by window: threads used = min(cores, windows)
-            threads = min(cores, windows)
-            reps = 3                         # ~0.5 s each on 16 threads: ~25 core-seconds in total
-            tc = time.perf_counter()
-            for _ in range(reps):
-                ref = co.msm_g1(hb, hs, ns, threads)
-            tcpu = (time.perf_counter() - tc) / reps
-            chk = ctx.msm_g1_device(d_bases.data_ptr(), d_scalars.data_ptr(), ns)
-            if chk != ref:
-                raise SystemExit("bench.py: GPU and CPU-oracle MSM disagree on the baseline sample")
-            line["cpu_baseline"] = {"value": ns / tcpu, "unit": "pts/s", "cores": threads, "kind": "port",
-                                    "sample": "first 2^%d points of the same workload, mean of %d MSMs, C oracle "
-                                              "(oracle/c, Pippenger threaded by window)" % (sample_log, reps),
-                                    "seconds": tcpu * reps}
-        print(json.dumps(line), flush=True)
-    if world > 1 or force_dist:
-        dist.barrier(**args.barrier_kw)
-        dist.destroy_process_group()
-    ctx.close()
+    rc = 0
+    env = None
+    try:
+        env = Env(args, zk, dist, rank, world, local_rank, dev)
+        if os.environ.get("ZKPOA_MSM_C"):        # experiments only: force the Pippenger window width
+            env.ctx.set_option("msm_c", int(os.environ["ZKPOA_MSM_C"]))
+        if args.workload.startswith("prove_2p"):
+            line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
+                             precompute=not args.no_precompute)
+        elif args.workload.startswith("msm_g1_2p"):
+            line = msm_leg(env, int(args.workload[len("msm_g1_2p"):]), args.steps, args.warmup, args.inflight,
+                           fixed_base=args.fixed_base, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+        else:
+            raise SystemExit("unknown workload " + args.workload)
+        # ---- the rest of BASELINE.json's metric, same process, N = 1 only (bounded: about two minutes in total)
+        if world == 1 and not force_dist and not args.no_also and args.workload == "msm_g1_2p20" and not args.fixed_base:
+            also = []
+            for name, fn in (
+                    ("msm_g1_2p20_fixed_base", lambda: msm_leg(env, 20, args.steps, args.warmup, args.inflight, fixed_base=True)),
+                    ("msm_g1_2p26", lambda: msm_leg(env, 26, 5, 2, 3)),
+                    ("msm_g1_2p26_fixed_base", lambda: msm_leg(env, 26, 5, 2, 3, fixed_base=True)),
+                    ("prove_2p21", lambda: prove_leg(env, 21, 20, 3)),
+                    ("prove_2p26", lambda: prove_leg(env, 26, 3, 1))):
+                t0 = time.perf_counter()
+                leg = fn()
+                entry = {"workload": name}
+                entry.update({kk: leg[kk] for kk in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config",
+                                                      "roofline")})
+                entry["leg_seconds"] = time.perf_counter() - t0
+                also.append(entry)
+            line["also"] = also
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+    except BenchError as e:
+        sys.stderr.write("bench.py: %s\n" % e)
+        rc = 1
+    finally:
+        # no barrier here: a rank that failed must not leave its peers waiting; tearing the group down is enough
+        if dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        if env is not None:
+            try:
+                env.ctx.close()
+            except Exception:
+                pass
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

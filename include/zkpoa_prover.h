@@ -141,6 +141,12 @@ int zkpoa_split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d
 int zkpoa_split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_received, void* d_exchange);
 int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_received);
 
+/* Fixed-base tables for a resident key (zkpoa_msm_table_build applied to sections 9, 8 and the A / B queries, in
+ * that order while they fit budget_bytes; 0 = half of the HBM free at the call). Later proves on the handle use
+ * them; proofs are bit-identical with and without. groth16_prover_zkey_file's key cache does this by itself the
+ * second time a key is used (env ZKPOA_PRECOMP=0 disables). used_bytes (optional) <- HBM taken by the tables. */
+int zkpoa_zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t budget_bytes, uint64_t* used_bytes);
+
 /* The H-MSM scalars of the LAST prove on this key handle (joinABC output, groth16_prove.js; domain x 32 B standard
  * form, or domain / world for a split shard: odd-coset indices i = rank mod world), copied to the host. Parity
  * tests use it to check pi_c at sizes where no CPU transform is affordable (oracle quotient identity). */
@@ -174,6 +180,21 @@ int zkpoa_ntt_device(zkpoa_context* ctx, void* d_data, unsigned log_n, int inver
 int zkpoa_msm_g1_device_lane(zkpoa_context* ctx, int lane, const void* d_bases, const void* d_scalars, uint64_t n,
                              uint8_t out[64]);
 float zkpoa_last_ms_lane(const zkpoa_context* ctx, int lane, int id);
+
+/* Fixed-base form of the same MSMs for bases that stay resident (a proving key's sections 5-9 never change, and
+ * 288 GB of HBM has room): zkpoa_msm_table_build stores 2^(c*j) * P_i for every window j of width c = window_bits
+ * (0 = cost model) once, window-major, in the zkey wire format; zkpoa_msm_table_run_lane then computes
+ * sum k_i * P_i for n scalars with ALL windows sharing one bucket set (fewer, wider windows: ~12-15 % fewer group
+ * additions, 1/W of the bucket-reduction work). Results are bit-identical to zkpoa_msm_g1/g2_device on the
+ * original bases. group: 1 = G1 (64-B points, out 64 B), 2 = G2 (128 B). info: out = {n, window_bits, windows, bytes}.
+ * The prover builds the same tables for a resident key: zkpoa_zkey_precompute. */
+typedef struct zkpoa_msm_table zkpoa_msm_table;
+int zkpoa_msm_table_build(zkpoa_context* ctx, int group, const void* d_bases, uint64_t n, int window_bits,
+                          zkpoa_msm_table** table);
+void zkpoa_msm_table_free(zkpoa_context* ctx, zkpoa_msm_table* table);
+int zkpoa_msm_table_info(const zkpoa_msm_table* table, uint64_t out[4]);
+int zkpoa_msm_table_run_lane(zkpoa_context* ctx, int lane, const zkpoa_msm_table* table, const void* d_scalars,
+                             uint8_t* out);
 
 /* Synthetic bases for benchmarks at sizes where no CPU generator is affordable:
  * P_i = (a + i*b) * G, i in [i0, i0+n), written affine/Montgomery into d_out (n*64 or n*128 B).

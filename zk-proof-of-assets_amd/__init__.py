@@ -40,7 +40,8 @@ EXPORTS = [
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
-    "zkpoa_zkey_read_h_scalars",
+    "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
+    "zkpoa_msm_table_build", "zkpoa_msm_table_free", "zkpoa_msm_table_info", "zkpoa_msm_table_run_lane",
 ]
 
 
@@ -131,6 +132,15 @@ def lib():
         L.zkpoa_groth16_verify_points.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_ulong, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_zkey_vkey.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ul_p]
+        L.zkpoa_zkey_precompute.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.POINTER(ctypes.c_uint64)]
+        L.zkpoa_msm_table_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
+                                            c_void_pp]
+        L.zkpoa_msm_table_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_msm_table_free.restype = None
+        L.zkpoa_msm_table_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.zkpoa_msm_table_run_lane.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]
         L.zkpoa_zkey_read_h_scalars.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_proof_to_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ul_p]
         L.zkpoa_public_to_json.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_int, ctypes.c_void_p, ul_p]
@@ -237,6 +247,17 @@ class Context:
 
     def last_ms_lane(self, lane, ident):
         return float(lib().zkpoa_last_ms_lane(self._h, lane, ident))
+
+    def msm_table(self, group, d_bases, n, window_bits=0):
+        """Fixed-base table over n device-resident bases (group 1 = G1, 2 = G2) -> MsmTable."""
+        return MsmTable(self, group, d_bases, n, window_bits)
+
+    def msm_table_run(self, table, d_scalars, lane=0):
+        """sum k_i P_i over a table's bases, fixed-base form; thread-safe across different lanes."""
+        out = ctypes.create_string_buffer(64 if table.group == 1 else 128)
+        if lib().zkpoa_msm_table_run_lane(self._h, lane, table._h, d_scalars, out) != PROVER_OK:
+            raise ZkpoaError("zkpoa_msm_table_run_lane failed")
+        return out.raw
 
     def msm_g2_device(self, d_bases, d_scalars, n):
         out = ctypes.create_string_buffer(128)
@@ -374,6 +395,33 @@ class Context:
         return proof.raw, pub.raw[:32 * npub]
 
 
+class MsmTable:
+    """Fixed-base table 2^(c*j) * P_i of a resident base array (zkpoa_msm_table_build)."""
+
+    def __init__(self, ctx, group, d_bases, n, window_bits=0):
+        self._ctx, self.group = ctx, group
+        self._h = ctypes.c_void_p()
+        ctx._check(lib().zkpoa_msm_table_build(ctx._h, group, d_bases, n, window_bits, ctypes.byref(self._h)),
+                   "zkpoa_msm_table_build")
+
+    def info(self):
+        """(n, window_bits, windows, bytes)"""
+        out = (ctypes.c_uint64 * 4)()
+        lib().zkpoa_msm_table_info(self._h, out)
+        return tuple(int(v) for v in out)
+
+    def close(self):
+        if self._h and self._ctx._h:
+            lib().zkpoa_msm_table_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ZKey:
     """A proving key resident in HBM (zkey sections 4-9 uploaded once)."""
 
@@ -397,6 +445,13 @@ class ZKey:
         """set_shard + the H-scalar chain split over the same ranks (world in 2, 4, 8)."""
         self._ctx._check(lib().zkpoa_zkey_set_shard_split(self._ctx._h, self._h, rank, world),
                          "zkpoa_zkey_set_shard_split")
+
+    def precompute(self, budget_bytes=0):
+        """Build the key's fixed-base tables (H, C, A, B while they fit; 0 = half of the free HBM) -> bytes used."""
+        used = ctypes.c_uint64(0)
+        self._ctx._check(lib().zkpoa_zkey_precompute(self._ctx._h, self._h, budget_bytes, ctypes.byref(used)),
+                         "zkpoa_zkey_precompute")
+        return int(used.value)
 
     def vkey_points(self):
         """The verification key the zkey carries (sections 2-3): alpha1(64) beta2(128) gamma2(128) delta2(128) +

@@ -33,9 +33,15 @@ namespace zkpoa {
 struct MsmPlan {
   uint32_t n = 0;   // points
   uint32_t c = 0;   // window bits
-  uint32_t W = 0;   // windows
-  uint32_t Nb = 0;  // buckets per window = 2^(c-1)
-  uint32_t TB = 0;  // total buckets
+  uint32_t W = 0;   // digit windows per scalar
+  uint32_t Nb = 0;  // buckets per bucket set = 2^(c-1)
+  // Fixed-base form (MsmTable below): the bases 2^(c*j) * P_i of every window j are precomputed, so the digits of
+  // ALL windows fall into ONE bucket set: Wb = 1 and the (point, window) entry w * n + i is itself the index into
+  // the table. Classic form: one bucket set per window, Wb = W.
+  bool merged = false;
+  uint32_t Wb = 0;  // bucket sets
+  uint32_t ne = 0;  // entries per bucket set: n (classic) or n * W (merged)
+  uint32_t TB = 0;  // total buckets = Wb * Nb
   uint32_t K0 = 0;  // level-0 piece length
   uint32_t K = 4;   // fan-in per thread for levels >= 1: hot buckets (witness bits) are latency-bound chains of full
                     // additions, so a small fan-in with more levels beats 64 sequential additions per thread
@@ -43,25 +49,34 @@ struct MsmPlan {
   uint32_t logS = 0, logRows = 0;
 };
 
-inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false) {
+inline uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
+
+// Window width. Costs in units of one mixed addition: every (point, window) entry is one; a bucket costs ~8 in the
+// reduction (two full additions + its share of the latency-bound weighting / tree kernels); one counting-sort pass
+// moves ~16 B per entry at ~3 TB/s, i.e. ~0.06 of an addition.
+inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, bool merged = false) {
   MsmPlan p;
   p.n = (uint32_t)n;
+  p.merged = merged;
   int best_c = 4;
   double best = 1e300;
-  for (int c = 4; c <= 22; c++) {
-    int W = (254 + c - 1) / c;
-    // accumulation adds + ~6 group ops per bucket in the reduction (full adds cost ~1.4 mixed adds)
-    double cost = (double)W * (double)n + 8.0 * (double)W * (double)(1u << (c - 1));
+  for (int c = 4; c <= (merged ? 25 : 22); c++) {
+    double W = (double)msm_windows((uint32_t)c);
+    double sets = merged ? 1.0 : W;
+    double passes = (double)((c - 1 + 7) / 8);
+    double cost = W * (double)n * (1.0 + 0.06 * passes) + 8.0 * sets * (double)(1u << (c - 1));
     if (cost < best) {
       best = cost;
       best_c = c;
     }
   }
-  if (force_c >= 4 && force_c <= 22) best_c = force_c;
+  if (force_c >= 4 && force_c <= (merged ? 25 : 22)) best_c = force_c;
   p.c = best_c;
-  p.W = (254 + p.c - 1) / p.c;
+  p.W = msm_windows(p.c);
   p.Nb = 1u << (p.c - 1);
-  p.TB = p.W * p.Nb;
+  p.Wb = merged ? 1u : p.W;
+  p.ne = merged ? p.n * p.W : p.n;
+  p.TB = p.Wb * p.Nb;
   p.logS = (uint32_t)(p.c - 1 + 1) / 2;
   p.logRows = (uint32_t)(p.c - 1) - p.logS;
   // Level-0 piece length. One thread adds one piece sequentially: about twice the mean bucket occupancy, so
@@ -69,7 +84,7 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false) {
   // K0 dependent mixed additions have run, and a G2 addition is ~15 us for a lone wave (256 of them: 4 ms), so
   // a sort whose result also feeds a G2 accumulation (the prover's B query) uses a quarter of that; buckets
   // longer than K0 continue in the partial-sum levels.
-  double avg = (double)n / (double)p.Nb;
+  double avg = (double)p.ne / (double)p.Nb;
   uint32_t k0 = 32;
   while (k0 < 2 * avg && k0 < 256) k0 <<= 1;
   if (for_g2 && k0 > 32) k0 = k0 >= 128 ? k0 / 4 : 32;
@@ -515,7 +530,7 @@ inline size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 inline size_t msm_sort_workspace_bytes(const MsmPlan& p) {
   size_t T = (size_t)p.n * p.W;
   size_t p1 = T / p.K0 + p.TB + 1;
-  SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  SortPlan sp = make_sort_plan(p.ne, p.Wb, p.c);
   size_t bytes = 0;
   bytes += al256((size_t)p.TB * 4);                  // counts
   bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // off0, po_a
@@ -546,8 +561,8 @@ inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
   bytes += al256((size_t)p.TB * MsmSizes<F>::kXyzz);  // buckets
   bytes += al256(p1 * MsmSizes<F>::kXyzz);            // P1
   bytes += al256(p2 * MsmSizes<F>::kXyzz);            // P2
-  bytes += al256(2 * p.W * E * MsmSizes<F>::kXyzz);                    // X: row / column sums
-  bytes += al256(2 * p.W * ((E + 255) / 256) * MsmSizes<F>::kXyzz) * 2;  // tree-sum levels
+  bytes += al256(2 * p.Wb * E * MsmSizes<F>::kXyzz);                    // X: row / column sums
+  bytes += al256(2 * p.Wb * ((E + 255) / 256) * MsmSizes<F>::kXyzz) * 2;  // tree-sum levels
   return bytes + (1 << 12);
 }
 
@@ -562,18 +577,21 @@ inline void lane_reserve(Lane& lane, size_t need) {
 // The arena is reset here; the result stays valid until the lane's next msm_sort_phase. With
 // sync_at_end the stream is synchronised on return, so other lanes may read the result.
 inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int force_c,
-                                size_t (*extra)(const MsmPlan&), bool sync_at_end = false, bool for_g2 = false) {
+                                size_t (*extra)(const MsmPlan&), bool sync_at_end = false, bool for_g2 = false,
+                                bool merged = false) {
   MsmSorted sr;
-  sr.p = msm_make_plan(n, force_c, for_g2);
+  sr.p = msm_make_plan(n, force_c, for_g2, merged);
   const MsmPlan& p = sr.p;
-  // entry positions are 32-bit: n * W (+ a few per-bucket slots) must stay below 2^32
+  // entry positions are 32-bit: n * W (+ a few per-bucket slots) must stay below 2^32; a merged entry index also
+  // carries the sign in bit 31
   if ((uint64_t)p.n * p.W + p.TB >= 0xffff0000ull) throw HipError("msm: n * windows exceeds the 32-bit entry index");
+  if (merged && (uint64_t)p.n * p.W >= 0x80000000ull) throw HipError("msm: n * windows exceeds the fixed-base entry index");
   hipStream_t st = lane.stream;
   lane_reserve(lane, msm_sort_workspace_bytes(p) + (extra ? extra(p) : 0));
   Arena& ws = lane.ws;
   ws.reset();
   const size_t T_max = (size_t)p.n * p.W;
-  const SortPlan sp = make_sort_plan(p.n, p.W, p.c);
+  const SortPlan sp = make_sort_plan(p.ne, p.Wb, p.c);
   sr.counts = ws.take<uint32_t>(p.TB);
   sr.off0 = ws.take<uint32_t>(p.TB + 1);
   sr.po_a = ws.take<uint32_t>(p.TB + 1);
@@ -684,7 +702,7 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   char* P1 = ws.take<char>(p1_cap * MsmSizes<F>::kXyzz);
   char* P2 = ws.take<char>(p2_cap * MsmSizes<F>::kXyzz);
   const uint32_t E = 1u << p.logS;            // entries per (window, row|column) group; logS >= logRows
-  const uint32_t groups = 2u * p.W;
+  const uint32_t groups = 2u * p.Wb;
   char* X = ws.take<char>((size_t)groups * E * MsmSizes<F>::kXyzz);
   const uint32_t S1 = (E + 255) / 256;
   char* Y1 = ws.take<char>((size_t)(S1 * groups) * MsmSizes<F>::kXyzz);
@@ -724,9 +742,9 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   // bucket reduction: row / column sums, weights, totals per (window, group)
   {
     uint32_t log_parts = p.logRows < kReduceLogParts ? p.logRows : kReduceLogParts;
-    uint64_t threads = ((uint64_t)p.W << log_parts) * ((1u << p.logRows) + E);
+    uint64_t threads = ((uint64_t)p.Wb << log_parts) * ((1u << p.logRows) + E);
     hipLaunchKernelGGL((msm_bucket_sums_kernel<F>), dim3((uint32_t)((threads + 255) / 256)), dim3(256),
-                       256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.W, p.Nb, p.logS, p.logRows, log_parts, E,
+                       256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.Wb, p.Nb, p.logS, p.logRows, log_parts, E,
                        (void*)X);
     uint32_t total = groups * E;
     hipLaunchKernelGGL((msm_bucket_weight_kernel<F>), dim3((total + 255) / 256), dim3(256), 0, st, (void*)X, p.logS,
@@ -752,13 +770,112 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));
 }
 
-// One complete MSM on one lane (phase A + phase B). Returns the plan used.
+// ---- fixed-base tables -------------------------------------------------------------------------------------
+// A proving key's bases never change (zkey sections 5-9), and an MI355X has 288 GB of HBM: store 2^(c*j) * P_i for
+// every window j once per key (window-major, affine Montgomery wire format, so table[j * n + i] is an ordinary
+// base array). Then all windows share ONE bucket set, which (a) lets the window grow (2^20: c 15 -> 17..19, 17 ->
+// 14..15 windows; 2^26: c 20 -> 24, 13 -> 11 windows: that many fewer mixed additions in the kernel that is >90 %
+// of an MSM), (b) divides the bucket-reduction work by W, (c) leaves the host a single window to combine.
+struct MsmTable {
+  void* d = nullptr;     // W * n points
+  uint64_t n = 0;        // points per window (= the base array it was built from)
+  uint32_t c = 0, W = 0;
+  size_t bytes = 0;
+};
+
+// table[j * n + i] = 2^(c * j) * P_i: one thread per point walks the windows (c doublings each) and writes XYZZ into
+// `scratch` (slab x W points), converted to affine afterwards (xyzz_to_affine: one inversion per point; once per key).
+template <class F>
+static __global__ __launch_bounds__(256) void msm_table_chain_kernel(const void* __restrict__ bases, uint64_t i0,
+                                                                      uint64_t cnt, uint32_t c, uint32_t W,
+                                                                      void* __restrict__ scratch) {
+  uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= cnt) return;
+  XYZZ<F> acc = XYZZ<F>::from_affine(load_affine<F>(bases, i0 + t));
+  for (uint32_t j = 0; j < W; j++) {
+    store_xyzz(scratch, (size_t)j * cnt + t, acc);
+    if (j + 1 < W)
+      for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
+  }
+}
+
+template <class F>
+static __global__ __launch_bounds__(256) void msm_table_affine_kernel(const void* __restrict__ scratch, uint64_t i0,
+                                                                       uint64_t cnt, uint64_t n, uint32_t W,
+                                                                       void* __restrict__ table) {
+  uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= cnt * W) return;
+  const uint64_t j = t / cnt, i = t % cnt;
+  XYZZ<F> p = load_xyzz<F>(scratch, t);
+  constexpr int FB = FieldBytes<F>::N;
+  char* o = reinterpret_cast<char*>(table) + (j * n + i0 + i) * (size_t)(2 * FB);
+  if (p.is_inf()) {
+    store_field(o, F::zero());
+    store_field(o + FB, F::zero());
+    return;
+  }
+  F i3 = p.zzz.inv();
+  F i2 = (p.zz * i3).sqr();
+  store_field(o, p.x * i2);
+  store_field(o + FB, p.y * i3);
+}
+
+template <class F>
+inline size_t msm_table_bytes(uint64_t n, uint32_t c) {
+  return (size_t)n * msm_windows(c) * MsmSizes<F>::kAffine;
+}
+
+// Window width of a table over n bases (the merged-bucket cost model), or `force_c`.
+inline uint32_t msm_table_c(uint64_t n, int force_c = 0, bool for_g2 = false) {
+  return msm_make_plan((size_t)n, force_c, for_g2, true).c;
+}
+
+// Builds the table on `st` (synchronised on return). Slabs of 2^20 points bound the scratch memory.
+template <class F>
+inline MsmTable msm_table_build(hipStream_t st, const void* d_bases, uint64_t n, uint32_t c) {
+  MsmTable t;
+  t.n = n;
+  t.c = c;
+  t.W = msm_windows(c);
+  t.bytes = msm_table_bytes<F>(n, c);
+  if ((uint64_t)n * t.W >= 0x80000000ull) throw HipError("msm table: n * windows exceeds the fixed-base entry index");
+  ZK_HIP(hipMalloc(&t.d, t.bytes ? t.bytes : 1));
+  const uint64_t slab = 1ull << 20;
+  void* scratch = nullptr;
+  try {
+    ZK_HIP(hipMalloc(&scratch, (size_t)(n < slab ? (n ? n : 1) : slab) * t.W * MsmSizes<F>::kXyzz));
+    for (uint64_t off = 0; off < n; off += slab) {
+      const uint64_t cnt = n - off < slab ? n - off : slab;
+      hipLaunchKernelGGL((msm_table_chain_kernel<F>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, st, d_bases, off,
+                         cnt, t.c, t.W, scratch);
+      hipLaunchKernelGGL((msm_table_affine_kernel<F>), dim3((uint32_t)((cnt * t.W + 255) / 256)), dim3(256), 0, st,
+                         (const void*)scratch, off, cnt, n, t.W, t.d);
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+  } catch (...) {
+    if (scratch) (void)hipFree(scratch);
+    (void)hipFree(t.d);
+    throw;
+  }
+  (void)hipFree(scratch);
+  return t;
+}
+
+inline void msm_table_free(MsmTable& t) {
+  if (t.d) (void)hipFree(t.d);
+  t = MsmTable();
+}
+
+// One complete MSM on one lane (phase A + phase B). Returns the plan used. With a table (built from exactly these
+// n bases) the fixed-base form runs: d_bases is then not read.
 template <class F>
 inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
-                          int force_c = 0, float* accum_ms = nullptr) {
-  MsmSorted sr = msm_sort_phase(lane, d_scalars, n, force_c, &msm_accum_workspace_bytes<F>, false,
-                                FieldBytes<F>::N > 32);
-  msm_accum_phase<F>(lane, sr, d_bases, window_sums_host, true, accum_ms);
+                          int force_c = 0, float* accum_ms = nullptr, const MsmTable* table = nullptr) {
+  if (table && table->n != n) throw HipError("msm: the fixed-base table was built for another base array");
+  MsmSorted sr = msm_sort_phase(lane, d_scalars, n, table ? (int)table->c : force_c, &msm_accum_workspace_bytes<F>,
+                                false, FieldBytes<F>::N > 32, table != nullptr);
+  msm_accum_phase<F>(lane, sr, table ? table->d : d_bases, window_sums_host, true, accum_ms);
   return sr.p;
 }
 

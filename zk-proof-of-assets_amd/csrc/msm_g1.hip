@@ -3,16 +3,40 @@
 
 namespace zkpoa {
 void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
-                float* ms2) {
-  msm_run<Fq, HFq>(ctx, lane_id, d_bases, d_scalars, n, out, ms2);
+                float* ms2, const MsmTable* table) {
+  msm_run<Fq, HFq>(ctx, lane_id, d_bases, d_scalars, n, out, ms2, table);
 }
-MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n, bool for_g2) {
+MsmTable* msm_table_build_g1(zkpoa_context* ctx, const void* d_bases, uint64_t n, int c) {
+  MsmTable* t = new MsmTable();
+  try {
+    *t = msm_table_build<Fq>(ctx->dev.lanes[0].stream, d_bases, n, msm_table_c(n, c, false));
+  } catch (...) {
+    delete t;
+    throw;
+  }
+  return t;
+}
+size_t msm_table_bytes_g1(uint64_t n, int c) { return msm_table_bytes<Fq>(n, msm_table_c(n, c, false)); }
+uint32_t msm_table_width(uint64_t n, int c, bool g2) { return msm_table_c(n, c, g2); }
+void msm_table_release(MsmTable* t) {
+  if (!t) return;
+  msm_table_free(*t);
+  delete t;
+}
+const void* msm_table_data(const MsmTable* t) { return t ? t->d : nullptr; }
+void msm_table_info(const MsmTable* t, uint64_t out[4]) {
+  out[0] = t->n;
+  out[1] = t->c;
+  out[2] = t->W;
+  out[3] = t->bytes;
+}
+MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n, bool for_g2, int table_c) {
   // the sorting lane also accumulates a G1 array afterwards: reserve room for that in the same arena
   MsmSorted* sr = new MsmSorted();
   try {
     if (lane_id) ctx->dev.wait_lanes();
-    *sr = msm_sort_phase(ctx->dev.lanes[lane_id], d_scalars, (size_t)n, ctx->opt_msm_c, &msm_accum_workspace_bytes<Fq>,
-                         true, for_g2);
+    *sr = msm_sort_phase(ctx->dev.lanes[lane_id], d_scalars, (size_t)n, table_c > 0 ? table_c : ctx->opt_msm_c,
+                         &msm_accum_workspace_bytes<Fq>, true, for_g2, table_c > 0);
   } catch (...) {
     delete sr;
     throw;

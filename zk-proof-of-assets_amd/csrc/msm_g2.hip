@@ -3,9 +3,20 @@
 
 namespace zkpoa {
 void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
-                float* ms2) {
-  msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out, ms2);
+                float* ms2, const MsmTable* table) {
+  msm_run<Fq2, HFq2>(ctx, lane_id, d_bases, d_scalars, n, out, ms2, table);
 }
+MsmTable* msm_table_build_g2(zkpoa_context* ctx, const void* d_bases, uint64_t n, int c) {
+  MsmTable* t = new MsmTable();
+  try {
+    *t = msm_table_build<Fq2>(ctx->dev.lanes[0].stream, d_bases, n, msm_table_c(n, c, true));
+  } catch (...) {
+    delete t;
+    throw;
+  }
+  return t;
+}
+size_t msm_table_bytes_g2(uint64_t n, int c) { return msm_table_bytes<Fq2>(n, msm_table_c(n, c, true)); }
 void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
                   uint8_t* out, float* ms2) {
   msm_accum_run<Fq2, HFq2>(ctx, lane_id, *sr, own_arena, d_bases, out, ms2);

@@ -7,13 +7,15 @@ namespace zkpoa {
 // ms2 (optional): [0] = device time of the whole MSM, [1] = its level-0 bucket-accumulation kernel.
 // Entry positions are 32-bit (n x windows < 2^32), so an MSM over more than `opt_msm_max_points` points
 // (default 2^27; the largest domain a zkey may have is 2^28) runs in chunks whose results are added on the host.
+// `table` (optional): fixed-base table built from exactly these n bases -> merged-bucket form, d_bases unread.
 template <class F, class HF>
 void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
-             float* ms2) {
+             float* ms2, const MsmTable* table = nullptr) {
   if (lane_id) ctx->dev.wait_lanes();
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
   const uint64_t max_pts = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
+  if (table && (n > max_pts || table->n != n)) table = nullptr;   // a chunked MSM cannot index a whole-array table
   XYZZ<HF> total = XYZZ<HF>::inf();
   float tot_ms = 0, acc_sum = 0;
   uint64_t done = 0;
@@ -23,14 +25,14 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
     ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
     MsmPlan p = msm_device<F>(lane, reinterpret_cast<const char*>(d_bases) + done * MsmSizes<F>::kAffine,
                               reinterpret_cast<const char*>(d_scalars) + done * 32, (size_t)cnt, wsums.data(),
-                              ctx->opt_msm_c, &acc_ms);
+                              ctx->opt_msm_c, &acc_ms, table);
     ZK_HIP(hipEventRecord(ctx->ev_b[lane_id], lane.stream));
     ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));
     float tot = 0;
     ZK_HIP(hipEventElapsedTime(&tot, ctx->ev_a[lane_id], ctx->ev_b[lane_id]));
     tot_ms += tot;
     acc_sum += acc_ms;
-    XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.W, p.c, p.logS);
+    XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), p.Wb, p.c, p.logS);
     if (done == 0) total = r;
     else xyzz_add(total, r);
     done += cnt;
@@ -61,7 +63,7 @@ void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool ow
     ms2[0] = tot;
     ms2[1] = acc_ms;
   }
-  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.W, sr.p.c, sr.p.logS);
+  XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.Wb, sr.p.c, sr.p.logS);
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }
 

@@ -152,6 +152,19 @@ struct zkpoa_zkey {
     }
   };
   CompactQuery qA, qB;
+  // Fixed-base tables (msm.hip.h MsmTable; zkpoa_zkey_precompute): 2^(c*j) * P for every window j of a whole
+  // resident base array -- the compacted A / B queries, section 8, section 9. An MSM uses its table only when it
+  // covers exactly that array (a re-pointed shard of a resident key falls back to the classic form).
+  MsmTable *tA = nullptr, *tB1 = nullptr, *tB2 = nullptr, *tC = nullptr, *tH = nullptr;
+  uint64_t table_bytes = 0;
+  uint64_t proofs_done = 0;   // groth16_prover_zkey_file's cache precomputes when a key is used a second time
+  void release_tables() {
+    for (MsmTable** t : {&tA, &tB1, &tB2, &tC, &tH}) {
+      msm_table_release(*t);
+      *t = nullptr;
+    }
+    table_bytes = 0;
+  }
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
   }
@@ -166,6 +179,7 @@ struct zkpoa_zkey {
     split(domain, rank, world, hlo, hcnt);
   }
   void release() {
+    release_tables();
     void* pts[] = {dA, dB1, dB2, dC, dH};
     if (owns_points)
       for (void* p : pts)
@@ -565,6 +579,66 @@ WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
   return w;
 }
 
+// a table covers the whole resident array: the handle's current range must be that array
+bool split_c_partial(const zkpoa_zkey* zk) {
+  uint64_t info[4];
+  msm_table_info(zk->tC, info);
+  return info[0] != zk->ccnt;
+}
+bool split_h_partial(const zkpoa_zkey* zk) {
+  uint64_t info[4];
+  msm_table_info(zk->tH, info);
+  return info[0] != zk->hcnt;
+}
+
+// Fixed-base tables for a resident key, most valuable first, while they fit the budget (bytes; 0 = half of the HBM
+// that is free right now -- which leaves room for the per-lane sort / bucket workspaces). H and C first: the H MSM
+// closes the critical path and section 8 is the largest G1 array; then the A query; the B query needs both its
+// G1 and G2 table (they share one bucket sort). Returns the bytes allocated.
+uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
+  if (zk->split_world > 1 || zk->csr_local) throw ProverError(PROVER_ERROR, "precompute: not for split shards");
+  ctx->dev.wait_lanes();
+  ZK_HIP(hipDeviceSynchronize());
+  if (budget == 0) {
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    budget = (uint64_t)(0.5 * (double)free_b);
+  }
+  zk->release_tables();
+  const int force_c = ctx->opt_msm_c;
+  auto fits = [&](uint64_t bytes) { return zk->table_bytes + bytes <= budget; };
+  const uint64_t nH = zk->dH ? zk->hcnt : 0, nC = zk->ccnt, nA = zk->qA.res, nB = zk->qB.res;
+  // a table that does not fit after all (allocation failure) ends the list; the ones built so far stay
+  auto build = [&](MsmTable** slot, bool g2, const void* bases, uint64_t n, int c) -> bool {
+    try {
+      *slot = g2 ? msm_table_build_g2(ctx, bases, n, c) : msm_table_build_g1(ctx, bases, n, c);
+      zk->table_bytes += g2 ? msm_table_bytes_g2(n, c) : msm_table_bytes_g1(n, c);
+      return true;
+    } catch (const HipError&) {
+      (void)hipGetLastError();
+      *slot = nullptr;
+      return false;
+    }
+  };
+  bool more = true;
+  if (more && nH && zk->hlo == zk->hbase && fits(msm_table_bytes_g1(nH, force_c))) more = build(&zk->tH, false, zk->dH, nH, force_c);
+  if (more && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, force_c))) more = build(&zk->tC, false, zk->dC, nC, force_c);
+  if (more && nA && fits(msm_table_bytes_g1(nA, force_c))) more = build(&zk->tA, false, zk->qA.g1, nA, force_c);
+  if (more && nB) {
+    // one window width for both B tables: the G2 model's (shorter pieces), as the shared sort is planned for G2
+    const int cB = (int)msm_table_width(nB, force_c, true);
+    if (fits(msm_table_bytes_g1(nB, cB) + msm_table_bytes_g2(nB, cB))) {
+      more = build(&zk->tB1, false, zk->qB.g1, nB, cB) && build(&zk->tB2, true, zk->qB.g2, nB, cB);
+      if (!more && zk->tB1) {   // the pair is only usable together
+        zk->table_bytes -= msm_table_bytes_g1(nB, cB);
+        msm_table_release(zk->tB1);
+        zk->tB1 = nullptr;
+      }
+    }
+  }
+  return zk->table_bytes;
+}
+
 // Partial MSM results of this handle's shard: A(64) B1(64) B2(128) C(64) H(64). The witness is already
 // in zk->d_witness (device). The H-scalar chain runs in full on every rank (replicated).
 void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) {
@@ -614,21 +688,29 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   // opt_prove_serial (measurement only): every stage runs alone, one after the other, so the per-stage device times
   // are solo times and their sum / the overlapped wall time says how much the five lanes gain (bench.py).
   const bool serial = ctx->opt_prove_serial != 0;
+  // fixed-base tables apply when the MSM covers the whole array the table was built from
+  const MsmTable* useA = (zk->tA && zk->qA.lo == 0 && zk->qA.cnt == zk->qA.res) ? zk->tA : nullptr;
+  const bool useB = zk->tB1 && zk->tB2 && zk->qB.lo == 0 && zk->qB.cnt == zk->qB.res;
+  const MsmTable* useC = (zk->tC && zk->clo == zk->cbase && !split_c_partial(zk)) ? zk->tC : nullptr;
+  const MsmTable* useH = (!split && zk->tH && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr;
   std::thread tA = guarded(0, [&] {
     gather(1, zk->qA);
-    msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1]);
+    msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1], useA);
   });
   if (serial) tA.join();
   // (a B query beyond the 32-bit entry index of one sort cannot share it: two chunked MSMs instead)
   const uint64_t sort_limit = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
   const bool share_b = zk->qB.cnt <= sort_limit;
+  uint64_t tb_info[4] = {0, 0, 0, 0};
+  if (useB) msm_table_info(zk->tB1, tb_info);
+  const int table_c_b = useB && share_b ? (int)tb_info[1] : 0;
   float sort_b_ms = 0;   // the shared sort of the B query (host clock: the call returns with its stream synchronised)
   std::thread tB1 = guarded(1, [&] {
     MsmSorted* sr = nullptr;
     try {
       gather(2, zk->qB);
       auto ts0 = std::chrono::steady_clock::now();
-      if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true);
+      if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
       else ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[2].stream));   // the gathered scalars are read on lane 3 too
       sort_b_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - ts0).count();
       sorted_promise.set_value(sr);
@@ -636,18 +718,18 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       sorted_promise.set_exception(std::current_exception());
       throw;
     }
-    if (share_b) msm_accum_g1(ctx, 2, sr, true, pB1, outB1, msm_ms[2]);
+    if (share_b) msm_accum_g1(ctx, 2, sr, true, table_c_b ? msm_table_data(zk->tB1) : pB1, outB1, msm_ms[2]);
     else msm_run_g1(ctx, 2, pB1, zk->qB.scalars, zk->qB.cnt, outB1, msm_ms[2]);
     if (share_b) msm_ms[2][0] += sort_b_ms;
   });
   if (serial) tB1.join();
   std::thread tB2 = guarded(2, [&] {
     const MsmSorted* sr = sorted_ready.get();
-    if (share_b) msm_accum_g2(ctx, 3, sr, false, pB2, outB2, msm_ms[3]);
+    if (share_b) msm_accum_g2(ctx, 3, sr, false, table_c_b ? msm_table_data(zk->tB2) : pB2, outB2, msm_ms[3]);
     else msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
   });
   if (serial) tB2.join();
-  std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4]); });
+  std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC); });
   if (serial) tC.join();
 
   std::exception_ptr main_err;
@@ -662,7 +744,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0]);
       zk->h_ready = false;
     } else {
-      msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0]);
+      msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0], useH);
     }
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
   } catch (...) {
@@ -1083,8 +1165,25 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
       if (cap) g_key_cache.push_back({sb.st_dev, sb.st_ino, sb.st_size, sb.st_mtim, zk, ++g_key_clock});
       else owned = true;
     }
+    // a key that comes out of the cache is being reused: build its fixed-base tables now, once (ZKPOA_PRECOMP=0 off)
+    if (hit && !owned && zk->proofs_done == 1 && zk->table_bytes == 0) {
+      const char* e = getenv("ZKPOA_PRECOMP");
+      if (!e || strcmp(e, "0") != 0) {
+        auto tp0 = std::chrono::steady_clock::now();
+        try {
+          uint64_t used = zkey_precompute(ctx, zk, 0);
+          if (getenv("ZKPOA_VERBOSE"))
+            fprintf(stderr, "zkpoa: fixed-base tables for the cached key: %.2f GB in %.0f ms\n", used / 1e9,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+        } catch (const HipError&) {   // out of HBM: the classic form keeps working
+          zk->release_tables();
+          (void)hipGetLastError();
+        }
+      }
+    }
     rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                        error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
+    zk->proofs_done++;
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
@@ -1402,6 +1501,17 @@ extern "C" int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, co
                          hipMemcpyDeviceToHost));
       selfcheck(ctx, zkey, proof_points, pub.data());
     }
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t budget_bytes, uint64_t* used_bytes) {
+  if (!ctx || !zkey) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    uint64_t used = zkey_precompute(ctx, zkey, budget_bytes);
+    if (used_bytes) *used_bytes = used;
   }
   ZK_PROVER_CATCH(ctx)
   return PROVER_OK;

@@ -138,6 +138,54 @@ extern "C" int zkpoa_msm_g2(zkpoa_context* ctx, const void* bases, const void* s
   ZK_API_END(ctx)
 }
 
+// ---- fixed-base tables (resident bases: zkey sections never change) ----------------------------------------------
+extern "C" int zkpoa_msm_table_build(zkpoa_context* ctx, int group, const void* d_bases, uint64_t n, int window_bits,
+                                     zkpoa_msm_table** out) {
+  if (!out) return PROVER_ERROR;
+  *out = nullptr;
+  ZK_API_BEGIN(ctx)
+  check_n(n);
+  if (group != 1 && group != 2) throw HipError("msm_table_build: group must be 1 or 2");
+  zkpoa_msm_table* h = new zkpoa_msm_table();
+  h->group = group;
+  try {
+    h->t = group == 1 ? msm_table_build_g1(ctx, d_bases, n, window_bits) : msm_table_build_g2(ctx, d_bases, n, window_bits);
+  } catch (...) {
+    delete h;
+    throw;
+  }
+  *out = h;
+  ZK_API_END(ctx)
+}
+extern "C" void zkpoa_msm_table_free(zkpoa_context* ctx, zkpoa_msm_table* table) {
+  if (!table) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->dev.device);
+    (void)hipDeviceSynchronize();
+  }
+  msm_table_release(table->t);
+  delete table;
+}
+extern "C" int zkpoa_msm_table_info(const zkpoa_msm_table* table, uint64_t out[4]) {
+  if (!table || !table->t || !out) return PROVER_ERROR;
+  msm_table_info(table->t, out);
+  return PROVER_OK;
+}
+extern "C" int zkpoa_msm_table_run_lane(zkpoa_context* ctx, int lane, const zkpoa_msm_table* table,
+                                        const void* d_scalars, uint8_t* out) {
+  if (!ctx || !table || !table->t || !out || lane < 0 || lane >= DeviceCtx::kLanes) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    uint64_t info[4];
+    msm_table_info(table->t, info);
+    if (table->group == 1) msm_run_g1(ctx, lane, nullptr, d_scalars, info[0], out, ctx->lane_ms[lane], table->t);
+    else msm_run_g2(ctx, lane, nullptr, d_scalars, info[0], out, ctx->lane_ms[lane], table->t);
+  } catch (const std::exception& e) {
+    return PROVER_ERROR;   // last_error is shared between lanes: not touched
+  }
+  return PROVER_OK;
+}
+
 // ---- synthetic bases / element-wise hooks --------------------------------------------------------
 extern "C" int zkpoa_gen_bases_g1_device(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32],
                                          uint64_t i0, uint64_t n, void* d_out) {

@@ -10,6 +10,7 @@
 
 namespace zkpoa {
 struct NttEngine;
+struct MsmTable;
 }
 
 struct zkpoa_context {
@@ -24,6 +25,11 @@ struct zkpoa_context {
   int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
   hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
   hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
+};
+
+struct zkpoa_msm_table {   // C-ABI handle of a fixed-base table (zkpoa_msm_table_build)
+  zkpoa::MsmTable* t = nullptr;
+  int group = 1;
 };
 
 namespace zkpoa {
@@ -41,10 +47,20 @@ struct DevBuf {  // RAII device allocation for the host-buffer entry points
 
 
 // per-group entry points, each compiled in its own translation unit (msm_g1.hip, msm_g2.hip, ...)
+struct MsmTable;   // msm.hip.h: fixed-base table 2^(c*j) * P_i of one base array
 void msm_run_g1(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
-                float* ms2);
+                float* ms2, const MsmTable* table = nullptr);
 void msm_run_g2(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
-                float* ms2);
+                float* ms2, const MsmTable* table = nullptr);
+// tables: built on lane 0's stream (synchronised on return); c = 0 picks the width from the cost model
+MsmTable* msm_table_build_g1(zkpoa_context* ctx, const void* d_bases, uint64_t n, int c);
+MsmTable* msm_table_build_g2(zkpoa_context* ctx, const void* d_bases, uint64_t n, int c);
+size_t msm_table_bytes_g1(uint64_t n, int c);
+size_t msm_table_bytes_g2(uint64_t n, int c);
+uint32_t msm_table_width(uint64_t n, int c, bool g2);
+void msm_table_release(MsmTable* t);
+const void* msm_table_data(const MsmTable* t);
+void msm_table_info(const MsmTable* t, uint64_t out[4]);   // n, c, W, bytes
 void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
@@ -53,8 +69,9 @@ void gen_bases_g2(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le
 // (stream synchronised on return), then accumulate each base array on its own lane.
 struct MsmSorted;
 // for_g2: the result also feeds a G2 accumulation (shorter pieces: a G2 addition has 3x the latency)
+// table_c > 0: sort for the fixed-base (merged-bucket) form with that window width
 MsmSorted* msm_sort_run(zkpoa_context* ctx, int lane_id, const void* d_scalars, uint64_t n,
-                        bool for_g2 = false);  // delete with msm_sorted_free
+                        bool for_g2 = false, int table_c = 0);  // delete with msm_sorted_free
 void msm_sorted_free(MsmSorted* sr);
 void msm_accum_g1(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
                   uint8_t* out, float* ms2);
