@@ -65,16 +65,25 @@ def np_scalars(n, seed):
 def host_cores():
     """Cores this process may run on (the GPU box gives a job a share of the host, not all of it)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:                                   # cgroup v2 CPU quota: "max 100000" or "<quota> <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("ZKPOA_BENCH_THREADS"):
+        n = int(os.environ["ZKPOA_BENCH_THREADS"])
+    return n
 
 
 def classic_window(n):
     """Window width the library's cost model picks for a classic n-point MSM (csrc/msm.hip.h msm_make_plan)."""
     def cost(c):
         w = (254 + c - 1) // c
-        return w * n * (1.0 + 0.06 * ((c - 1 + 7) // 8)) + 8.0 * w * (1 << (c - 1))
+        return w * n * (1.0 + 0.03 * ((c - 1 + 7) // 8)) + 3.0 * w * (1 << (c - 1))
     return min(range(4, 23), key=cost)
 
 
@@ -475,6 +484,8 @@ def main():
         env = Env(args, zk, dist, rank, world, local_rank, dev)
         if os.environ.get("ZKPOA_MSM_C"):        # experiments only: force the Pippenger window width
             env.ctx.set_option("msm_c", int(os.environ["ZKPOA_MSM_C"]))
+        if os.environ.get("ZKPOA_MSM_K0"):       # experiments only: force the level-0 piece length
+            env.ctx.set_option("msm_k0", int(os.environ["ZKPOA_MSM_K0"]))
         if args.workload.startswith("prove_2p"):
             line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
                              precompute=not args.no_precompute)

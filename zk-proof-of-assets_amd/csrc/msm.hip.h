@@ -30,6 +30,7 @@
 
 namespace zkpoa {
 
+constexpr uint32_t kMaxPieceLenPlan = 512;   // = kMaxPieceLen of the piece-ordering kernels
 struct MsmPlan {
   uint32_t n = 0;   // points
   uint32_t c = 0;   // window bits
@@ -50,10 +51,15 @@ struct MsmPlan {
 };
 
 inline uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
+// experiments (zkpoa_set_option "msm_k0"): force the level-0 piece length; 0 = the rule below
+inline int& msm_forced_k0() {
+  static int k0 = 0;
+  return k0;
+}
 
-// Window width. Costs in units of one mixed addition: every (point, window) entry is one; a bucket costs ~8 in the
-// reduction (two full additions + its share of the latency-bound weighting / tree kernels); one counting-sort pass
-// moves ~16 B per entry at ~3 TB/s, i.e. ~0.06 of an addition.
+// Window width. Costs in units of one mixed addition: every (point, window) entry is one; a bucket costs ~3 in the
+// reduction (a row and a column full addition at 1.4 each + tree levels); one counting-sort pass moves ~20 B per
+// entry at ~3 TB/s, i.e. ~0.03 of an addition per entry and pass (measured per-kernel times at 2^20, r02).
 inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, bool merged = false) {
   MsmPlan p;
   p.n = (uint32_t)n;
@@ -64,7 +70,7 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
     double W = (double)msm_windows((uint32_t)c);
     double sets = merged ? 1.0 : W;
     double passes = (double)((c - 1 + 7) / 8);
-    double cost = W * (double)n * (1.0 + 0.06 * passes) + 8.0 * sets * (double)(1u << (c - 1));
+    double cost = W * (double)n * (1.0 + 0.03 * passes) + 3.0 * sets * (double)(1u << (c - 1));
     if (cost < best) {
       best = cost;
       best_c = c;
@@ -88,6 +94,13 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   uint32_t k0 = 32;
   while (k0 < 2 * avg && k0 < 256) k0 <<= 1;
   if (for_g2 && k0 > 32) k0 = k0 >= 128 ? k0 / 4 : 32;
+  // ... and short enough that the pieces fill the chip about 2.5 times over (256 CUs x 12 waves x 64 lanes at the
+  // accumulation kernel's 3 waves per SIMD; 2 for G2): with fewer, longer pieces the grid is one partial wave of
+  // work and the CUs idle behind its longest pieces (2^20 points: 128-long pieces ran at 0.84 of the ALU ceiling,
+  // 32-long ones at 0.95-1.0; the extra partial sums cost ~3 % more additions).
+  const double fill = (double)p.n * p.W / (2.5 * 256.0 * (for_g2 ? 8.0 : 12.0) * 64.0);
+  while (k0 > 32 && (double)k0 > fill) k0 >>= 1;
+  if (msm_forced_k0() >= 8 && msm_forced_k0() <= (int)kMaxPieceLenPlan) k0 = (uint32_t)msm_forced_k0();
   p.K0 = k0;
   return p;
 }
@@ -400,25 +413,23 @@ static __global__ __launch_bounds__(256) void msm_accumN_kernel(const void* __re
 }
 
 // ---- 5: bucket reduction ----------------------------------------------------------------------
-constexpr uint32_t kReduceLogParts = 4;   // threads per row / column sum (each adds len / 16 buckets, then an LDS tree;
-                                          // 8..32 measured alike, 64 slower)
-template <class F>
-__device__ __noinline__ void xyzz_add_ni(XYZZ<F>& a, const XYZZ<F>& b) {
-  xyzz_add(a, b);
-}
-template <class F>
-__device__ __noinline__ void xyzz_dbl_ni(XYZZ<F>& a) {
-  a = xyzz_dbl(a);
-}
-
 // Window sum = sum_b (b + 1) * B_b. With b = hi * S + lo (rows x S matrix of the window's buckets):
 //   sum_b (b + 1) B_b = S * sum_hi hi * R_hi + sum_lo (lo + 1) * C_lo,   R_hi = row sums, C_lo = column sums.
-// All 2 * Nb additions of the row / column sums are independent short chains (PARTS threads per sum, T terms
-// each, then an LDS tree over the parts), the weights are <= max(logS, logRows) bits (double-and-add per sum),
-// and the two weighted totals U = sum hi R_hi, V = sum (lo+1) C_lo per window go to the host, which forms
-// 2^logS * U + V. Compared with a running sum per segment this halves the group operations and has no long
-// dependent chain (a 2^20 MSM has only 17 x 2^14 buckets: latency, not throughput, decides).
+// All 2 * Nb additions of the row / column sums are independent: 2^logParts threads per sum add `per` (8-16)
+// buckets each, then an LDS tree over the parts -- enough threads to fill the chip whatever the bucket count (a
+// fixed-base MSM at c = 20 has 2^19 buckets: 1536 sums x 64 parts), every thread a short chain. The weights are
+// <= max(logS, logRows) bits (double-and-add per sum), and the two weighted totals U = sum hi R_hi,
+// V = sum (lo+1) C_lo per bucket set go to the host, which forms 2^logS * U + V.
+// Every kernel below has ONE inlined call site per group operation (a loop whose operand comes from HBM first and
+// from LDS afterwards): no scratch memory, ~140 VGPRs, so these waves co-reside with the accumulation kernel's.
 // out[(w * 2 + grp) * E + idx]: grp 0 = R (idx = hi < rows), grp 1 = C (idx = lo < S); E >= max(rows, S).
+constexpr uint32_t kReduceMaxLogParts = 8;   // one sum per 256-thread workgroup at most
+inline uint32_t msm_reduce_log_parts(uint32_t logRows) {
+  uint32_t lp = logRows > 3 ? logRows - 3 : 0;   // per = 8 column terms (16 row terms when S = 2 * rows)
+  if (lp < 4) lp = logRows < 4 ? logRows : 4;
+  return lp > kReduceMaxLogParts ? kReduceMaxLogParts : lp;
+}
+
 template <class F>
 static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void* __restrict__ buckets, uint32_t W,
                                                                      uint32_t Nb, uint32_t logS, uint32_t logRows,
@@ -435,21 +446,21 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
   const uint32_t len = is_row ? S : rows, stride = is_row ? 1u : S;
   const size_t base = (size_t)w * Nb + (is_row ? (size_t)idx * S : (size_t)idx);
   const uint32_t per = len >> logParts;   // logParts <= min(logS, logRows)
+  const uint32_t per_max = S >> logParts; // uniform trip count (S >= rows)
   XYZZ<F> acc = XYZZ<F>::inf();
-  if (valid) {
-    for (uint32_t j = part * per; j < (part + 1u) * per; j++) {
-      XYZZ<F> bkt = load_xyzz<F>(buckets, base + (size_t)j * stride);
-      xyzz_add_ni(acc, bkt);
+  // iterations [0, per_max): this thread's buckets from HBM; then logParts tree levels through LDS
+  for (uint32_t it = 0; it < per_max + logParts; it++) {
+    XYZZ<F> other = XYZZ<F>::inf();
+    if (it < per_max) {
+      if (valid && it < per) other = load_xyzz<F>(buckets, base + (size_t)(part * per + it) * stride);
+    } else {
+      const uint32_t st = parts >> (it - per_max + 1u);
+      store_xyzz(lds_raw, threadIdx.x, acc);
+      __syncthreads();
+      if (part < st) other = load_xyzz<F>(lds_raw, threadIdx.x + st);
+      __syncthreads();
     }
-  }
-  for (uint32_t st = parts >> 1; st > 0; st >>= 1) {
-    store_xyzz(lds_raw, threadIdx.x, acc);
-    __syncthreads();
-    if (part < st) {
-      XYZZ<F> o2 = load_xyzz<F>(lds_raw, threadIdx.x + st);
-      xyzz_add_ni(acc, o2);
-    }
-    __syncthreads();
+    xyzz_add(acc, other);
   }
   if (valid && part == 0) store_xyzz(out, ((size_t)w * 2u + (is_row ? 0u : 1u)) * E + idx, acc);
 }
@@ -466,13 +477,13 @@ static __global__ __launch_bounds__(256) void msm_bucket_weight_kernel(void* __r
   uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
   XYZZ<F> r = XYZZ<F>::inf();
   if (k) {
-    XYZZ<F> v = load_xyzz<F>(X, gid);
+    const XYZZ<F> v = load_xyzz<F>(X, gid);
+    const XYZZ<F> none = XYZZ<F>::inf();
     if (!v.is_inf()) {
-      r = v;
       int top = 31 - __builtin_clz(k);
-      for (int bit = top - 1; bit >= 0; bit--) {
-        xyzz_dbl_ni(r);
-        if ((k >> bit) & 1u) xyzz_add_ni(r, v);
+      for (int bit = top; bit >= 0; bit--) {   // r = 2 r (+ v): one doubling site, one addition site
+        r = xyzz_dbl(r);
+        xyzz_add(r, ((k >> bit) & 1u) ? v : none);
       }
     }
   }
@@ -488,15 +499,13 @@ static __global__ __launch_bounds__(256) void msm_tree_sum_kernel(const void* __
   uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   XYZZ<F> v = XYZZ<F>::inf();
   if (idx < S) v = load_xyzz<F>(X, (size_t)w * S + idx);
-  store_xyzz(lds_raw, threadIdx.x, v);
-  __syncthreads();
   for (uint32_t stride = 128; stride > 0; stride >>= 1) {
-    if (threadIdx.x < stride) {
-      XYZZ<F> o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
-      xyzz_add_ni(v, o);
-      store_xyzz(lds_raw, threadIdx.x, v);
-    }
+    store_xyzz(lds_raw, threadIdx.x, v);
     __syncthreads();
+    XYZZ<F> o = XYZZ<F>::inf();
+    if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
+    __syncthreads();
+    xyzz_add(v, o);
   }
   if (threadIdx.x == 0) store_xyzz(Y, (size_t)w * S_out + blockIdx.x, v);
 }
@@ -741,7 +750,7 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   }
   // bucket reduction: row / column sums, weights, totals per (window, group)
   {
-    uint32_t log_parts = p.logRows < kReduceLogParts ? p.logRows : kReduceLogParts;
+    uint32_t log_parts = msm_reduce_log_parts(p.logRows);
     uint64_t threads = ((uint64_t)p.Wb << log_parts) * ((1u << p.logRows) + E);
     hipLaunchKernelGGL((msm_bucket_sums_kernel<F>), dim3((uint32_t)((threads + 255) / 256)), dim3(256),
                        256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.Wb, p.Nb, p.logS, p.logRows, log_parts, E,

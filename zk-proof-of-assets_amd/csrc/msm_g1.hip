@@ -24,6 +24,7 @@ void msm_table_release(MsmTable* t) {
   delete t;
 }
 const void* msm_table_data(const MsmTable* t) { return t ? t->d : nullptr; }
+void msm_set_forced_k0(int k0) { msm_forced_k0() = k0; }
 void msm_table_info(const MsmTable* t, uint64_t out[4]) {
   out[0] = t->n;
   out[1] = t->c;

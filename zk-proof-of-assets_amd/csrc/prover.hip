@@ -599,12 +599,14 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
   if (zk->split_world > 1 || zk->csr_local) throw ProverError(PROVER_ERROR, "precompute: not for split shards");
   ctx->dev.wait_lanes();
   ZK_HIP(hipDeviceSynchronize());
+  zk->release_tables();
   if (budget == 0) {
+    // the lanes' grow-only workspaces are given back first (they regrow to what the fixed-base plans need)
+    for (auto& l : ctx->dev.lanes) l.ws.release();
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
     budget = (uint64_t)(0.5 * (double)free_b);
   }
-  zk->release_tables();
   const int force_c = ctx->opt_msm_c;
   auto fits = [&](uint64_t bytes) { return zk->table_bytes + bytes <= budget; };
   const uint64_t nH = zk->dH ? zk->hcnt : 0, nC = zk->ccnt, nA = zk->qA.res, nB = zk->qB.res;

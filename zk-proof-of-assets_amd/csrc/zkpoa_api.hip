@@ -70,6 +70,10 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
     ctx->opt_msm_max_points = value;
     return PROVER_OK;
   }
+  if (!strcmp(key, "msm_k0")) {           // experiments: level-0 piece length of the bucket accumulation (process-wide)
+    msm_set_forced_k0((int)value);
+    return PROVER_OK;
+  }
   if (!strcmp(key, "prove_serial")) {     // measurement: no overlap between the stages of a prove
     ctx->opt_prove_serial = value != 0;
     return PROVER_OK;

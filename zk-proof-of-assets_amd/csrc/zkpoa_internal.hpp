@@ -61,6 +61,7 @@ uint32_t msm_table_width(uint64_t n, int c, bool g2);
 void msm_table_release(MsmTable* t);
 const void* msm_table_data(const MsmTable* t);
 void msm_table_info(const MsmTable* t, uint64_t out[4]);   // n, c, W, bytes
+void msm_set_forced_k0(int k0);
 void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
