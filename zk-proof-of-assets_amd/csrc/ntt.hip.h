@@ -13,8 +13,10 @@
 // Between passes the four-step twiddle W_n^((n/N') * ka * rev_B(m)) is applied on the way out
 // (DIF) or in (DIT), looked up as Hi[e >> L] * Lo[e & (2^L - 1)] from two small tables, so inside
 // a pass every butterfly twiddle is a plain 2^B-th root from a 2^(B-1)-entry table.
-// The prover chain ifft -> coset shift -> fft is DIF(w^-1) -> pointwise -> DIT(w) and needs no
-// bit-reversal permutation at all; the natural-order API adds one in-place permutation kernel.
+// The prover chain ifft -> coset shift -> fft is DIF(w^-1) -> DIT(w) with the coset factor inc^j / n multiplied in
+// as the forward transform's first pass loads its tile: no bit-reversal permutation and no scaling pass at all.
+// The natural-order API (Fr.fft / Fr.ifft) stores its last pass at the bit-reversed position (times 1/n).
+// Boundary twiddles of a pass whose table fits the cache (2^21 entries) are read as ONE value per element.
 #pragma once
 #include "bn254_field.hip.h"
 #include "device_ctx.hpp"
@@ -28,6 +30,7 @@ namespace zkpoa {
 constexpr uint32_t kNttTileLog = 11;  // 2048 elements = 64 KiB of LDS per workgroup
 constexpr uint32_t kNttStridedB = 8;  // rows per tile in strided passes (x 8 columns)
 constexpr uint32_t kNttMaxStridedB = 10;  // a single strided pass may take up to 10 stages (x 2 columns)
+constexpr uint32_t kNttDirectMaxLog = 21;  // boundary twiddles as one table up to 2^21 entries (64 MiB, cache-resident)
 // threads per 2048-element tile: 8 waves share the 64 KiB tile, so with 2 tiles per CU every SIMD has 4 waves
 // to cover the multiply latency and the per-stage barriers (measured at 2^26: 256 threads +10 %, 1024 +10 %)
 constexpr uint32_t kNttThreads = 512;
@@ -65,14 +68,36 @@ ZK_DEV void lds_store(uint4* lds, uint32_t idx, const Fr& v) {
   lds[2 * idx + 1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// What a pass folds into its load / store besides the butterflies (each saves a whole 64 B/element round trip):
+//   kPassPlain      nothing
+//   kPassPreScale   DIT pass over stages [0, B): every element is multiplied on load by X^j, j = bitrev_k(p), from a
+//                   two-level table (the coset shift inc^j / n between the inverse and the forward transform)
+//   kPassBitrevOut  DIF pass over stages [0, B): the result is stored at bitrev_k(p), times `post` (1/n of the
+//                   inverse; one) -- the natural-order output of Fr.fft / Fr.ifft without a permutation kernel
+enum NttPassMode { kPassPlain = 0, kPassPreScale = 1, kPassBitrevOut = 2 };
+
+// boundary twiddle table of a strided pass laid out like the tile rows: D[(r << s_lo) + col] = W^((col * r) << shift)
+static __global__ __launch_bounds__(256) void ntt_direct_table_kernel(void* __restrict__ out, uint32_t s_lo, uint32_t B,
+                                                                      uint32_t shift, const void* __restrict__ hi,
+                                                                      const void* __restrict__ lo, uint32_t L) {
+  uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >> (s_lo + B)) return;
+  uint32_t col = i & ((1u << s_lo) - 1u), r = i >> s_lo;
+  store_field(reinterpret_cast<char*>(out) + 32 * (size_t)i, tw_lookup(hi, lo, L, (col * r) << shift));
+}
+
 // One pass over stages [s_lo, s_lo + B). Tile: 2^B rows (stride 2^s_lo elements) x 2^logT columns
-// (consecutive elements); requires logT <= s_lo. grid.x = n / 2^(B+logT).
-template <bool DIF>
-static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(void* __restrict__ data, uint32_t k, uint32_t s_lo,
+// (consecutive elements); requires logT <= s_lo. grid.x = n / 2^(B+logT). tw_direct (optional): the boundary
+// twiddles of this pass as one table (a single multiplication per element instead of hi * lo and then the product).
+template <bool DIF, int MODE>
+static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void* src, void* dst, uint32_t k, uint32_t s_lo,
                                                               uint32_t B, uint32_t logT,
                                                               const void* __restrict__ small_tw,
                                                               const void* __restrict__ tw_hi,
-                                                              const void* __restrict__ tw_lo, uint32_t L) {
+                                                              const void* __restrict__ tw_lo, uint32_t L,
+                                                              const void* __restrict__ tw_direct,
+                                                              const void* __restrict__ sc_hi,
+                                                              const void* __restrict__ sc_lo, uint32_t Lc, Fr post) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const uint32_t T = 1u << logT, tile = 1u << (B + logT), tid = threadIdx.x;
   const uint32_t cg_count = (1u << s_lo) >> logT;
@@ -80,17 +105,19 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(void* __re
   const uint64_t U = blockIdx.x / cg_count;
   const uint64_t base = (U << (s_lo + B)) + (uint64_t)cg * T;
   const uint32_t shift = k - (s_lo + B);  // log2(n / N')
-  char* d = reinterpret_cast<char*>(data);
+  const char* sp = reinterpret_cast<const char*>(src);
+  char* d = reinterpret_cast<char*>(dst);
 
   for (uint32_t e = tid; e < tile; e += kNttThreads) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
-    Fr v = load_field<Fr>(d + 32 * p);
+    Fr v = load_field<Fr>(sp + 32 * p);
     if (!DIF && s_lo > 0) {
       uint32_t r = __brev(m) >> (32u - B);
-      uint32_t ex = ((cg * T + c) * r) << shift;
-      v = v * tw_lookup(tw_hi, tw_lo, L, ex);
+      if (tw_direct) v = v * load_field<Fr>(reinterpret_cast<const char*>(tw_direct) + 32 * (((size_t)r << s_lo) + cg * T + c));
+      else v = v * tw_lookup(tw_hi, tw_lo, L, ((cg * T + c) * r) << shift);
     }
+    if (MODE == kPassPreScale) v = v * tw_lookup(sc_hi, sc_lo, Lc, __brev((uint32_t)p) >> (32u - k));
     lds_store(lds, e, v);
   }
   __syncthreads();
@@ -128,44 +155,17 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(void* __re
     Fr v = lds_load(lds, e);
     if (DIF && s_lo > 0) {
       uint32_t r = __brev(m) >> (32u - B);
-      uint32_t ex = ((cg * T + c) * r) << shift;
-      v = v * tw_lookup(tw_hi, tw_lo, L, ex);
+      if (tw_direct) v = v * load_field<Fr>(reinterpret_cast<const char*>(tw_direct) + 32 * (((size_t)r << s_lo) + cg * T + c));
+      else v = v * tw_lookup(tw_hi, tw_lo, L, ((cg * T + c) * r) << shift);
     }
-    store_field(d + 32 * p, v);
+    if (MODE == kPassBitrevOut) {
+      // the images of different tiles interleave: with more than one tile, dst must not be the buffer being read
+      v = v * post;
+      store_field(d + 32 * (size_t)(__brev((uint32_t)p) >> (32u - k)), v);
+    } else {
+      store_field(d + 32 * p, v);
+    }
   }
-}
-
-// in-place bit-reversal permutation of n = 2^k elements
-static __global__ __launch_bounds__(256) void fr_bitrev_kernel(void* data, uint32_t k) {
-  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (p >> k) return;
-  uint64_t r = (uint64_t)(__brev((uint32_t)p) >> (32u - k));
-  if (k == 0 || p >= r) return;
-  char* d = reinterpret_cast<char*>(data);
-  Fr a = load_field<Fr>(d + 32 * p), b = load_field<Fr>(d + 32 * r);
-  store_field(d + 32 * p, b);
-  store_field(d + 32 * r, a);
-}
-
-// data[p] *= Hi[j >> L] * Lo[j & mask], j = bitrev_k(p) if BITREV else p
-// (batchApplyKey(first, inc) with first folded into Lo; also the 1/n of the inverse transform)
-template <bool BITREV>
-static __global__ __launch_bounds__(256) void fr_scale_pow_kernel(void* data, uint32_t k, const void* __restrict__ hi,
-                                                                  const void* __restrict__ lo, uint32_t L) {
-  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (p >> k) return;
-  uint32_t j = BITREV ? (k ? (__brev((uint32_t)p) >> (32u - k)) : 0u) : (uint32_t)p;
-  char* d = reinterpret_cast<char*>(data) + 32 * p;
-  Fr v = load_field<Fr>(d);
-  store_field(d, v * tw_lookup(hi, lo, L, j));
-}
-
-// data[p] *= c
-static __global__ __launch_bounds__(256) void fr_scale_const_kernel(void* data, uint64_t n, Fr c) {
-  uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (p >= n) return;
-  char* d = reinterpret_cast<char*>(data) + 32 * p;
-  store_field(d, load_field<Fr>(d) * c);
 }
 
 // ---- H-scalar chain split over G ranks (NTT row) -----------------------------------------
@@ -272,6 +272,7 @@ struct NttTables {  // device tables for one (k, direction)
   void* hi = nullptr;                 // W^(i * 2^L), i < 2^(k-L)
   void* lo = nullptr;                 // W^i, i < 2^L
   std::map<uint32_t, void*> small;    // B -> W_{2^B}^t, t < 2^(B-1)
+  std::map<uint32_t, void*> direct;   // s_lo -> boundary twiddles of the strided pass starting there (when small enough)
 };
 
 inline Fr to_dev(const HFr& h) {
@@ -316,6 +317,15 @@ struct NttEngine {
       build_pow_table(st, hpow2(w, k - ps.B), HFr::one(), cnt, p);  // W_{2^B} = W^(2^(k-B))
       t.small[ps.B] = p;
     }
+    for (const auto& ps : ntt_plan(k)) {
+      if (ps.s_lo == 0 || ps.s_lo + ps.B > kNttDirectMaxLog) continue;
+      void* p = nullptr;
+      const uint32_t cnt = 1u << (ps.s_lo + ps.B);
+      ZK_HIP(hipMalloc(&p, (size_t)cnt * 32));
+      hipLaunchKernelGGL(ntt_direct_table_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, p, ps.s_lo, ps.B,
+                         k - (ps.s_lo + ps.B), (const void*)t.hi, (const void*)t.lo, t.L);
+      t.direct[ps.s_lo] = p;
+    }
     return cache.emplace(key, t).first->second;
   }
 
@@ -332,18 +342,39 @@ struct NttEngine {
     return coset_cache.emplace(cache_key, std::make_pair(hi, lo)).first->second;
   }
 
+  // mode applies to the pass over stages [0, B) (the last DIF pass / the first DIT pass). kPassPreScale: (sc_hi,
+  // sc_lo, Lc) two-level table of the per-element factor. kPassBitrevOut: the transform reads `d_data`, uses `tmp`
+  // (n elements) for the intermediate passes and leaves the NATURAL-order result, times `post`, in d_data.
   template <bool DIF>
-  void run_passes(hipStream_t st, void* d_data, uint32_t k, bool inverse) {
+  void run_passes(hipStream_t st, void* d_data, uint32_t k, bool inverse, int mode = kPassPlain,
+                  const void* sc_hi = nullptr, const void* sc_lo = nullptr, uint32_t Lc = 0, void* tmp = nullptr,
+                  const HFr* post = nullptr) {
     if (k == 0) return;
     const NttTables& t = tables(st, k, inverse);
     auto plan = ntt_plan(k);
+    const Fr post_d = to_dev(post ? *post : HFr::one());
     for (size_t idx = 0; idx < plan.size(); idx++) {
       const NttPassDesc& ps = DIF ? plan[plan.size() - 1 - idx] : plan[idx];
       uint32_t tile_log = ps.B + ps.logT;
       uint32_t grid = 1u << (k - tile_log);
       size_t lds_bytes = (size_t)32 << tile_log;
-      hipLaunchKernelGGL((ntt_pass_kernel<DIF>), dim3(grid), dim3(kNttThreads), lds_bytes, st, d_data, k, ps.s_lo, ps.B,
-                         ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi, (const void*)t.lo, t.L);
+      auto dit = t.direct.find(ps.s_lo);
+      const void* direct = dit == t.direct.end() ? nullptr : dit->second;
+      const bool special = ps.s_lo == 0 && mode != kPassPlain;
+      const void* src = d_data;
+      void* dst = d_data;
+      if (mode == kPassBitrevOut && plan.size() > 1) {   // d -> tmp, tmp -> tmp ..., tmp -> d (bit-reversed positions)
+        src = idx == 0 ? d_data : tmp;
+        dst = idx + 1 == plan.size() ? d_data : tmp;
+      }
+#define ZK_NTT_PASS(MODE_)                                                                                              \
+  hipLaunchKernelGGL((ntt_pass_kernel<DIF, MODE_>), dim3(grid), dim3(kNttThreads), lds_bytes, st, src, dst, k, ps.s_lo,  \
+                     ps.B, ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi, (const void*)t.lo, t.L, direct,     \
+                     sc_hi, sc_lo, Lc, post_d)
+      if (special && mode == kPassPreScale) ZK_NTT_PASS(kPassPreScale);
+      else if (special && mode == kPassBitrevOut) ZK_NTT_PASS(kPassBitrevOut);
+      else ZK_NTT_PASS(kPassPlain);
+#undef ZK_NTT_PASS
     }
   }
 
@@ -352,24 +383,28 @@ struct NttEngine {
   // bit-reversed -> natural
   void dit(hipStream_t st, void* d, uint32_t k, bool inverse) { run_passes<false>(st, d, k, inverse); }
 
-  void bitrev(hipStream_t st, void* d, uint32_t k) {
-    uint64_t n = 1ull << k;
-    hipLaunchKernelGGL(fr_bitrev_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, k);
-  }
-
-  // Fr.fft / Fr.ifft semantics: natural order in and out
+  // Fr.fft / Fr.ifft semantics: natural order in and out. The bit-reversal and the 1/n of the inverse ride on the
+  // last DIF pass's store (no permutation kernel, no scaling kernel); multi-pass sizes go through a scratch buffer
+  // of n elements (grow-only, kept on the engine).
+  void* nat_tmp = nullptr;
+  size_t nat_tmp_bytes = 0;
   void transform_natural(hipStream_t st, void* d, uint32_t k, bool inverse) {
-    dif(st, d, k, inverse);
-    bitrev(st, d, k);
-    if (inverse) {
-      uint64_t n = 1ull << k;
-      HFr ninv = HFr::from_u64(n).inv();
-      hipLaunchKernelGGL(fr_scale_const_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, n,
-                         to_dev(ninv));
+    if (k == 0) return;
+    const uint64_t n = 1ull << k;
+    if (ntt_plan(k).size() > 1 && nat_tmp_bytes < n * 32) {
+      ZK_HIP(hipStreamSynchronize(st));
+      if (nat_tmp) ZK_HIP(hipFree(nat_tmp));
+      nat_tmp = nullptr;
+      nat_tmp_bytes = 0;
+      ZK_HIP(hipMalloc(&nat_tmp, n * 32));
+      nat_tmp_bytes = n * 32;
     }
+    HFr ninv = HFr::from_u64(n).inv();
+    run_passes<true>(st, d, k, inverse, kPassBitrevOut, nullptr, nullptr, 0, nat_tmp, inverse ? &ninv : nullptr);
   }
 
-  // evaluations on the domain -> evaluations on the odd coset (ifft, batchApplyKey(1, inc), fft)
+  // evaluations on the domain -> evaluations on the odd coset (ifft, batchApplyKey(1, inc), fft): the coset shift
+  // inc^j / n is applied by the forward transform's first pass as it loads (no separate scaling pass)
   void to_odd_coset(hipStream_t st, void* d, uint32_t k) {
     if (k == 0) return;  // n = 1: constant polynomial
     uint64_t n = 1ull << k;
@@ -377,9 +412,7 @@ struct NttEngine {
     HFr ninv = HFr::from_u64(n).inv();
     auto tb = pow_tables(st, k, inc, ninv, k);
     dif(st, d, k, true);
-    hipLaunchKernelGGL((fr_scale_pow_kernel<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d, k,
-                       (const void*)tb.first, (const void*)tb.second, (k + 1) / 2);
-    dit(st, d, k, false);
+    run_passes<false>(st, d, k, false, kPassPreScale, tb.first, tb.second, (k + 1) / 2);
   }
 
   // the part of to_odd_coset between the two exchanges when the transform is split over G ranks
@@ -417,7 +450,11 @@ struct NttEngine {
       (void)hipFree(kv.second.hi);
       (void)hipFree(kv.second.lo);
       for (auto& s : kv.second.small) (void)hipFree(s.second);
+      for (auto& s : kv.second.direct) (void)hipFree(s.second);
     }
+    if (nat_tmp) (void)hipFree(nat_tmp);
+    nat_tmp = nullptr;
+    nat_tmp_bytes = 0;
     for (auto& kv : coset_cache) {
       (void)hipFree(kv.second.first);
       (void)hipFree(kv.second.second);
