@@ -145,3 +145,40 @@ def test_prover_server_lifecycle_without_gpu(zk, tmp_path):
             break
         time.sleep(0.05)
     assert not os.path.exists(sock)
+
+
+def test_prover_server_failure_paths_without_gpu(zk, tmp_path):
+    """(1) a server that dies with a request in hand does not fail the call -- the client proves in its own
+    process (here: reaches the library, which has no GPU on this box); (2) a client that connects and says nothing
+    does not hold the single-threaded server. On a GPU box tests/test_gpu_prove.py checks that (1) yields a proof."""
+    import socket
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked server tests")
+    g = golden_case("n8")
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "w.wtns").write_bytes(g["witness.wtns"])
+    argv = [zk.PROVER_BIN, "c.zkey", "w.wtns", "proof.json", "public.json"]
+    # (1) the server exits on receipt of the request
+    sock = str(tmp_path / "crash.sock")
+    env = dict(os.environ, ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="30", ZKPOA_SERVER_TEST_CRASH="1")
+    rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert "went away without answering; proving in-process" in rc.stderr
+    assert rc.returncode == 1 and "no HIP device" in rc.stderr       # the in-process attempt ran (and has no GPU here)
+    # (2) a silent connection is dropped after the receive timeout and the next request is served
+    sock = str(tmp_path / "quiet.sock")
+    env = dict(os.environ, ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="30", ZKPOA_SERVER_RCV_TIMEOUT_S="1")
+    try:
+        rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert os.path.exists(sock)
+        quiet = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        quiet.connect(sock)                                           # ... and never sends a byte
+        t0 = time.time()
+        rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert rc.returncode == 1 and "no HIP device" in rc.stderr and "in-process" not in rc.stderr
+        assert time.time() - t0 < 20
+        quiet.close()
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)

@@ -665,3 +665,62 @@ def test_two_process_sharded_prove_rehearsal(extra):
     assert line["n_gpus"] == 2 and line["metric"] == "Groth16 proofs/sec"
     assert ("replicated" if extra else "split") in line["config"]["parallelism"]
     assert "REHEARSAL" in line["data"]
+
+
+# ---- failure paths that used to be silent or sticky ---------------------------------------------------
+def test_server_death_mid_request_still_yields_the_proof(zk, tmp_path):
+    """The resident server dies with a request in hand (ZKPOA_SERVER_TEST_CRASH): the client proves in its own
+    process, exit 0, same bytes; the next call starts a fresh server and is served by it."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    sock = str(tmp_path / "prover.sock")
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_SERVER=sock, ZKPOA_VERBOSE="1",
+               ZKPOA_SERVER_IDLE_S="60")
+    argv = [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"]
+    try:
+        rc = subprocess.run(argv, env=dict(env, ZKPOA_SERVER_TEST_CRASH="1"), capture_output=True, text=True,
+                            cwd=tmp_path, timeout=120)
+        assert rc.returncode == 0, rc.stderr
+        assert "went away without answering; proving in-process" in rc.stderr
+        assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+        os.remove(tmp_path / "proof.json")
+        rc = subprocess.run(argv, env=env, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert rc.returncode == 0 and "prover server pid" in rc.stderr, rc.stderr
+        assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
+def test_out_of_range_field_elements_are_rejected(ctx, zk):
+    """Untrusted files: a witness value, a section-4 coefficient or a point coordinate that is not a canonical field
+    element must fail loudly (PROVER_ERROR), not produce a wrong proof with exit code 0."""
+    g = golden_case("n128")
+    z = g["circuit.zkey"]
+    _, wit = g16.read_wtns(g["witness.wtns"])
+    secs = g16.read_binfile(z, "zkey", 2)
+    key = ctx.load_zkey(z)
+    try:
+        for bad_value in (R, R + 1, (1 << 256) - 1):
+            w = bytearray(g["witness.wtns"])
+            ws = g16.read_binfile(bytes(w), "wtns", 2)
+            p2, _ = ws[2][0]
+            w[p2 + 32 * 7:p2 + 32 * 8] = bad_value.to_bytes(32, "little")
+            with pytest.raises(zk.ZkpoaError, match="witness value is not a field element"):
+                ctx.prove(key, bytes(w), 1, 2)
+        pts, _ = ctx.prove(key, g["witness.wtns"], 1, 2)      # the handle is still good afterwards
+        assert len(pts) == 256
+    finally:
+        key.close()
+    p4, _ = secs[4][0]
+    bad = bytearray(z)
+    bad[p4 + 4 + 12:p4 + 4 + 44] = R.to_bytes(32, "little")
+    with pytest.raises(zk.ZkpoaError, match="coefficient value is not a field element"):
+        ctx.load_zkey(bytes(bad))
+    for sid in (5, 7, 9):
+        ps, _ = secs[sid][0]
+        bad = bytearray(z)
+        bad[ps + 32:ps + 64] = bn.Q.to_bytes(32, "little")
+        with pytest.raises(zk.ZkpoaError, match="coordinate is not a field element"):
+            ctx.load_zkey(bytes(bad))

@@ -24,6 +24,24 @@ struct CoefRec {  // 44 bytes, 4-byte aligned, as stored in zkey section 4 after
 };
 static_assert(sizeof(CoefRec) == 44, "coef record");
 
+// ---- range validation of untrusted field elements -------------------------------------------------------------
+// The device keeps field elements lazily in [0, 2p) and takes file data raw, so a value >= the modulus in a .wtns
+// or .zkey would flow through (a witness value >= r breaks the scalar recoding's r - s: a silently wrong proof with
+// exit code 0). One streaming pass ORs a flag instead: count elements of 32 B each, all must be < P.
+template <class PRM>
+static __global__ __launch_bounds__(256) void range_check_kernel(const void* __restrict__ data, uint64_t count,
+                                                                 uint32_t* __restrict__ flag) {
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const uint4* q = reinterpret_cast<const uint4*>(data) + 2 * i;
+  uint4 a = q[0], b = q[1];
+  const uint32_t l[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t bw = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) (void)subb(l[k], PRM::P[k], bw);
+  if (!bw) atomicOr(flag, 1u);   // no borrow: value >= P
+}
+
 constexpr uint32_t kAbcSkip = 0xffffffffu;   // rank of a record that belongs to another rank's constraint rows
 
 // pass 1: validate + histogram rows, remember the rank inside the row. err[0] != 0 on bad records.
@@ -36,8 +54,11 @@ static __global__ __launch_bounds__(256) void abc_count_kernel(const CoefRec* __
   uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= ncoef) return;
   uint32_t m = recs[i].m, c = recs[i].c, s = recs[i].s;
-  if (m > 1u || c >= domain || s >= nvars) {
-    atomicOr(err, 1u);
+  uint32_t bw = 0;   // the coefficient value must be a canonical Fr element
+#pragma unroll
+  for (int k = 0; k < 8; k++) (void)subb(recs[i].val[k], FrParams::P[k], bw);
+  if (m > 1u || c >= domain || s >= nvars || !bw) {
+    atomicOr(err, bw ? 1u : 2u);
     rank[i] = kAbcSkip;
     return;
   }

@@ -119,6 +119,7 @@ struct zkpoa_zkey {
   uint32_t n_long = 0;
   uint32_t* d_sig = nullptr;
   void* d_vals = nullptr;
+  uint32_t* d_flag = nullptr; // [0]: a witness value >= r was seen by the last prove (range_check_kernel)
   void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
   void* d_witness = nullptr;  // nVars * 32 B
   bool owns_points = true;    // false when the point sections belong to the caller (zkpoa_zkey_load_device)
@@ -184,18 +185,26 @@ struct zkpoa_zkey {
     if (owns_points)
       for (void* p : pts)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long};
+    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long, d_flag};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     qA.release();
     qB.release();
     dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = nullptr;
     d_long = nullptr;
+    d_flag = nullptr;
     d_row_ptr = d_sig = nullptr;
   }
 };
 
 namespace {
+
+// count x 32-byte elements at d must all be below the modulus (Fq: point coordinates, Fr: witness values)
+template <class PRM>
+void range_check(hipStream_t st, const void* d, uint64_t count, uint32_t* d_flag) {
+  if (count)
+    hipLaunchKernelGGL((range_check_kernel<PRM>), dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, d, count, d_flag);
+}
 
 // list of the constraints too long for one lane (key-dependent only); returns the count, *list owned by the caller
 uint32_t build_long_list(hipStream_t st, const uint32_t* d_row_ptr, uint32_t rows, uint32_t** list) {
@@ -230,6 +239,7 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool loca
   // n / G H scalars here (the transforms run in the caller's exchange buffers)
   if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, local_rows ? (size_t)(n >> lp) * 32 : (size_t)3 * n * 32));
   if (!zk->d_witness) ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
+  if (!zk->d_flag) ZK_HIP(hipMalloc(reinterpret_cast<void**>(&zk->d_flag), 64));
   DevBuf d_cnt((size_t)rows * 4), d_rank((size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4),
       d_bs(((size_t)rows / kScanTile + 2) * 4), d_misc(64);
   ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
@@ -249,6 +259,7 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool loca
   ZK_HIP(hipMemcpyAsync(&herr, misc + 4, 4, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
+  if (herr & 2u) throw ProverError(PROVER_ERROR, "zkey coefficient value is not a field element (>= r)");
   if (herr) throw ProverError(PROVER_ERROR, "zkey coefficient record out of range (matrix/constraint/signal)");
   zk->nCoefsLocal = total;
   zk->csr_local = local_rows;
@@ -443,6 +454,21 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
       zk->dH = dev_upload(ctx, s9.p + zk->hlo * 64, zk->hcnt * 64);
     }
     phase("point sections 5-9 -> HBM");
+    {   // every coordinate must be a canonical Fq element (< q)
+      hipStream_t st0 = ctx->dev.lanes[0].stream;
+      DevBuf flag(64);
+      ZK_HIP(hipMemsetAsync(flag.p, 0, 64, st0));
+      range_check<FqParams>(st0, zk->dA, zk->wcnt * 2, (uint32_t*)flag.p);
+      range_check<FqParams>(st0, zk->dB1, zk->wcnt * 2, (uint32_t*)flag.p);
+      range_check<FqParams>(st0, zk->dB2, zk->wcnt * 4, (uint32_t*)flag.p);
+      range_check<FqParams>(st0, zk->dC, zk->ccnt * 2, (uint32_t*)flag.p);
+      range_check<FqParams>(st0, split ? zk->dHs : zk->dH, (split ? n / world : zk->hcnt) * 2, (uint32_t*)flag.p);
+      uint32_t bad = 0;
+      ZK_HIP(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st0));
+      ZK_HIP(hipStreamSynchronize(st0));
+      if (bad) throw ProverError(PROVER_ERROR, "zkey point coordinate is not a field element (>= q)");
+      phase("coordinate range check");
+    }
     queries_compact(ctx, zk.get(), zk->wcnt);
     phase("A / B queries without infinity");
     hipStream_t st = ctx->dev.lanes[0].stream;
@@ -540,13 +566,26 @@ void split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
 
 HFr hfr_from_le(const uint8_t* le) { return HFr::from_bytes(le); }
 
+// uniform on [0, r): 254 random bits, rejected while >= r (about one draw in four is), as Groth16's zero-knowledge
+// argument assumes and as snarkjs' Fr.random() samples
 void random_scalar(uint8_t out[32]) {
   int fd = open("/dev/urandom", O_RDONLY);
   if (fd < 0) throw ProverError(PROVER_ERROR, "cannot open /dev/urandom");
-  ssize_t got = read(fd, out, 32);
+  for (;;) {
+    ssize_t got = read(fd, out, 32);
+    if (got != 32) {
+      close(fd);
+      throw ProverError(PROVER_ERROR, "short read from /dev/urandom");
+    }
+    out[31] &= 0x3f;   // 254 bits
+    bool below = false;
+    for (int i = 31; i >= 0; i--) {
+      if (out[i] < kR[i]) { below = true; break; }
+      if (out[i] > kR[i]) break;
+    }
+    if (below) break;
+  }
   close(fd);
-  if (got != 32) throw ProverError(PROVER_ERROR, "short read from /dev/urandom");
-  out[31] &= 0x1f;  // < 2^253 < r
 }
 
 bool parse_decimal_mod_r(const char* s, uint8_t out[32]) {
@@ -735,7 +774,11 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   if (serial) tC.join();
 
   std::exception_ptr main_err;
+  uint32_t witness_bad = 0;
   try {
+    // witness values must be canonical (< r): one streaming pass on the chain's lane, flag read with the H MSM's results
+    ZK_HIP(hipMemsetAsync(zk->d_flag, 0, 4, l0.stream));
+    range_check<FrParams>(l0.stream, zk->d_witness, zk->nVars, zk->d_flag);
     ZK_HIP(hipEventRecord(ctx->ev_a[5], l0.stream));
     if (!split)
       h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_long, zk->n_long, zk->d_witness, zk->domain,
@@ -749,6 +792,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0], useH);
     }
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
+    ZK_HIP(hipMemcpy(&witness_bad, zk->d_flag, 4, hipMemcpyDeviceToHost));   // lane 0 is idle: its MSM has returned
   } catch (...) {
     main_err = std::current_exception();
   }
@@ -765,6 +809,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   if (main_err) std::rethrow_exception(main_err);
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
+  if (witness_bad) throw ProverError(PROVER_ERROR, "witness value is not a field element (>= r)");
   auto t1 = std::chrono::steady_clock::now();
   ctx->ms[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();
   ctx->ms[0] = msm_ms[0][0];
@@ -1004,6 +1049,14 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
   int rc = PROVER_OK;
   uint8_t rb[32], sb[32];
   const uint8_t *rp = nullptr, *sp = nullptr;
+  if (getenv("ZKPOA_R") || getenv("ZKPOA_S")) {
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "zkpoa: WARNING: blinding scalars fixed by ZKPOA_R / ZKPOA_S (test use): proofs made this way are "
+                      "not zero-knowledge; unset them in production\n");
+    }
+  }
   if (const char* e = getenv("ZKPOA_R")) {
     if (!parse_decimal_mod_r(e, rb)) throw ProverError(PROVER_ERROR, "ZKPOA_R is not a decimal number");
     rp = rb;
@@ -1589,7 +1642,7 @@ extern "C" int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned 
     uint32_t herr = 0;
     ZK_HIP(hipMemcpyAsync(&herr, (uint32_t*)misc.p + 4, 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
-    if (herr) throw ProverError(PROVER_ERROR, "h_scalars: coefficient record out of range");
+    if (herr) throw ProverError(PROVER_ERROR, "h_scalars: coefficient record out of range or value >= r");
     ntt_prepare(ctx, st, log_domain);
     uint32_t* long_list = nullptr;
     uint32_t n_long = build_long_list(st, (const uint32_t*)row_ptr.p, rows, &long_list);

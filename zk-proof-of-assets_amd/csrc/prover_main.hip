@@ -81,8 +81,10 @@ static double now_ms() {
 }
 
 // ---- one proof in this process: (zkey path, wtns path) -> files; message = what goes to stderr ------------
+// *runtime_failure (optional) <- the failure came from the HIP runtime (sticky fault, out of memory, lost device),
+// not from the inputs: the process's GPU context cannot be trusted any more.
 static int prove_files(const char* zkey, const char* wtns_path, const char* proof_path, const char* public_path,
-                       std::string& message) {
+                       std::string& message, bool* runtime_failure = nullptr) {
   MappedFile wtns;
   if (!wtns.open_file(wtns_path)) {
     message = std::string("Error: cannot read witness file ") + wtns_path;
@@ -103,6 +105,8 @@ static int prove_files(const char* zkey, const char* wtns_path, const char* proo
   }
   if (rc != PROVER_OK) {
     message = std::string("Error: ") + err;
+    // the library's HIP failures read "<hip call> failed: <hipGetErrorString> at file:line" (device_ctx.hpp ZK_HIP)
+    if (runtime_failure) *runtime_failure = strstr(err, " failed: ") && strstr(err, "hip");
     return EXIT_FAILURE;
   }
   if (!write_atomic(proof_path, proof.data()) || !write_atomic(public_path, pub.data())) {
@@ -116,7 +120,8 @@ static int prove_files(const char* zkey, const char* wtns_path, const char* proo
 // Wire format, both directions: u32 length + payload. Request payload = NUL-separated fields
 //   "prove" zkey wtns proof public R S JSON VERBOSE   (absolute paths; option fields may be empty)
 //   "stop"
-// Reply payload = one status byte ('0' + exit code) followed by the message for stderr.
+// Reply payload = one status byte followed by the message for stderr: '0' + exit code, or 'R' = the server hit a
+// GPU runtime failure and is going away: the client proves in its own process (fresh HIP context) instead.
 static bool send_all(int fd, const void* buf, size_t len) {
   const char* p = static_cast<const char*>(buf);
   while (len) {
@@ -212,6 +217,7 @@ static int server_main(const std::string& sock) {
   int idle_s = 600;
   if (const char* e = getenv("ZKPOA_SERVER_IDLE_S")) idle_s = atoi(e) > 0 ? atoi(e) : idle_s;
   bool running = true;
+  int exit_code = 0;
   while (running) {
     struct pollfd pfd = {ls, POLLIN, 0};
     int pr = poll(&pfd, 1, idle_s * 1000);
@@ -222,6 +228,12 @@ static int server_main(const std::string& sock) {
     }
     int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
     if (c < 0) continue;
+    {   // a client that connects and then says nothing must not hold the (single-threaded) server
+      struct timeval tv = {10, 0};
+      if (const char* e = getenv("ZKPOA_SERVER_RCV_TIMEOUT_S")) tv.tv_sec = atoi(e) > 0 ? atoi(e) : 10;
+      (void)setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      (void)setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+    }
     struct ucred cred;
     socklen_t cl = sizeof(cred);
     std::string req, reply;
@@ -248,11 +260,20 @@ static int server_main(const std::string& sock) {
         set_or_clear("ZKPOA_VERBOSE", f[8]);   // the library's phase line goes to <socket>.log
         const double t0 = now_ms();
         std::string message;
-        int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message);
+        if (getenv("ZKPOA_SERVER_TEST_CRASH")) _exit(3);   // tests: the server dies with a request in hand
+        bool runtime_failure = false;
+        int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message, &runtime_failure);
         if (rc == EXIT_SUCCESS && !f[8].empty())
           message = "zkpoa: prover server pid " + std::to_string((long)getpid()) + " served the proof in " +
                     std::to_string(now_ms() - t0) + " ms";
         reply = std::string(1, (char)('0' + rc)) + message;
+        if (runtime_failure) {
+          // This process's HIP context (and every key cached in it) is suspect: hand the request back to the client
+          // and leave, so that the next call starts a fresh server instead of failing until the idle timeout.
+          reply = "R" + message;
+          running = false;
+          exit_code = 4;
+        }
       } else {
         reply = "1Error: malformed request to the prover server";
       }
@@ -263,6 +284,7 @@ static int server_main(const std::string& sock) {
   close(ls);
   unlink(sock.c_str());
   close(lock);
+  if (exit_code) _exit(exit_code);   // no HIP teardown on a context that has already failed
   return 0;
 }
 
@@ -318,12 +340,27 @@ static int client_main(char** argv, const std::string& sock, bool stop) {
     }
   }
   std::string reply;
+  {   // a server stuck on the GPU must not hang the workflow for ever: generous, since a layer-three proof with a cold
+      // 21 GB key takes tens of seconds (ZKPOA_SERVER_TIMEOUT_S)
+    int to = 1800;
+    if (const char* e = getenv("ZKPOA_SERVER_TIMEOUT_S")) to = atoi(e) > 0 ? atoi(e) : to;
+    struct timeval tv = {to, 0};
+    (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  }
   if (!send_msg(fd, req) || !recv_msg(fd, reply) || reply.empty()) {
+    // no reply arrived (the server died, or was exiting when we connected): nothing has been written, so this
+    // process can simply do the work itself
     close(fd);
-    fprintf(stderr, "Error: the prover server closed the connection\n");
-    return EXIT_FAILURE;
+    if (stop) return EXIT_SUCCESS;
+    fprintf(stderr, "zkpoa: the prover server went away without answering; proving in-process\n");
+    return -1;
   }
   close(fd);
+  if (reply[0] == 'R') {
+    fprintf(stderr, "zkpoa: the prover server reported a GPU runtime failure (%s) and is restarting; proving in-process\n",
+            reply.c_str() + 1);
+    return -1;
+  }
   if (reply.size() > 1) fprintf(stderr, "%s\n", reply.c_str() + 1);
   return reply[0] - '0';
 }
