@@ -121,17 +121,24 @@ int zkpoa_prove_assemble(const uint8_t header_points[448], const uint8_t partial
  * + joinABC. world = G in {2, 4, 8}, G^2 <= domain n, M = n / G, Q = M / G.
  * Rank g owns the constraint rows c = g (mod G) and ends with the H scalars of the odd-coset indices
  * i = g (mod G); its H points are the cyclic shard H[t*G + g], so no scalar ever moves after stage 3.
- * Each transform is a four-step NTT with ONE all-to-all (2 per polynomial for ifft -> shift -> fft):
+ * Each transform is a four-step NTT with ONE all-to-all (2 per proof for ifft -> shift -> fft of all three
+ * polynomials together):
  *   zkpoa_witness_load       parse a .wtns and upload it into the key's witness buffer (every rank: replicated)
  *   zkpoa_split_stage1       buildABC on the rank's rows + size-M inverse DIF of A, B, C -> d_exchange
- *   [caller: per polynomial, all-to-all with equal splits of Q elements (RCCL all_to_all_single)]
+ *   [caller: ONE all-to-all with equal splits over the whole buffer (RCCL all_to_all_single)]
  *   zkpoa_split_stage2       twiddle, size-G DFT, coset scale inc^k / n, size-G DFT, twiddle: d_received -> d_exchange
  *   [caller: the same all-to-all again]
  *   zkpoa_split_stage3       size-M forward DIT of A, B, C + joinABC -> H scalars kept on the key handle
  *   zkpoa_prove_partials_device(ctx, key, NULL, partials)   the five MSMs of the shard (H: cyclic shard)
- * d_exchange / d_received: caller-owned device buffers of 3 * M * 32 bytes (A, B, C polynomial-major), e.g.
- * the tensors handed to RCCL. Every stage returns with its stream synchronised; the caller synchronises the
- * collective's stream before the next stage. d_witness NULL = the witness already resident on the handle. */
+ * d_exchange / d_received: caller-owned device buffers of 3 * M * 32 bytes laid out [G ranks][3 polynomials A, B, C]
+ * [Q elements]: the contiguous chunk h (3 * Q * 32 bytes) is what rank h receives, e.g. the tensors handed to RCCL.
+ * The three stages ENQUEUE their kernels on the context's lane-0 stream and return (errors of the launch itself are
+ * reported; execution errors surface at the next synchronising call): run the collectives on that same stream
+ * (zkpoa_context_stream: e.g. torch.cuda.ExternalStream) and no host synchronisation is needed anywhere in the chain,
+ * or call zkpoa_context_synchronize before touching the buffers from another stream. The witness MSMs of
+ * zkpoa_prove_partials_device run on other lanes and overlap the chain. d_witness NULL = the witness already resident. */
+void* zkpoa_context_stream(zkpoa_context* ctx, int lane);   /* hipStream_t of lane 0..5 (NULL on error) */
+int zkpoa_context_synchronize(zkpoa_context* ctx);          /* waits for lane 0's stream */
 int zkpoa_zkey_load_shard_split(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
                                 uint64_t rank, uint64_t world, zkpoa_zkey** zkey);
 int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t rank, uint64_t world);

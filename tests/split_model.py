@@ -32,15 +32,19 @@ def _dit(x):
     return bn.ntt([x[_rev(j, L)] for j in range(n)])
 
 
-def to_buf(polys):
+def to_buf(polys, world):
+    """[3 polynomials][M values] -> exchange-buffer layout [world][3][Q * 32 bytes] (include/zkpoa_prover.h)"""
     import torch
-    return torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "little") for p in polys for v in p)),
-                            dtype=torch.uint8).view(len(polys), -1)
+    flat = torch.frombuffer(bytearray(b"".join(int(v).to_bytes(32, "little") for p in polys for v in p)),
+                            dtype=torch.uint8).view(len(polys), world, -1)
+    return flat.permute(1, 0, 2).contiguous()
 
 
 def from_buf(t):
-    raw = bytes(t.contiguous().view(-1).numpy().tobytes())
-    per = t.shape[1]
+    """exchange-buffer layout [world][3][Q * 32] -> [3][M values] (blocks ordered by rank)"""
+    t = t.permute(1, 0, 2).contiguous()
+    raw = bytes(t.view(-1).numpy().tobytes())
+    per = t.shape[1] * t.shape[2]
     return [[int.from_bytes(raw[x * per + 32 * i:x * per + 32 * i + 32], "little") for i in range(per // 32)]
             for x in range(t.shape[0])]
 
@@ -56,7 +60,7 @@ class SplitRank:
         self.h = None
 
     def stage1(self, out):
-        out.copy_(to_buf([_dif(x, True) for x in self.rows]))
+        out.copy_(to_buf([_dif(x, True) for x in self.rows], self.G))
 
     def stage2(self, recv, out):
         G, M, n, k = self.G, self.M, self.n, self.k
@@ -77,7 +81,7 @@ class SplitRank:
                     b = sum(a[k2] * pow(w, M * k2 * i2, R) for k2 in range(G)) % R
                     o[i2 * Q + pl] = b * pow(w, k1 * i2, R) % R
             res.append(o)
-        out.copy_(to_buf(res))
+        out.copy_(to_buf(res, self.G))
 
     def stage3(self, recv):
         Ao, Bo, Co = [_dit(p) for p in from_buf(recv)]

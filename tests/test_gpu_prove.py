@@ -227,11 +227,11 @@ def test_split_chain_long_rows(ctx, zk, long_row_circuit, world):
         for r in range(world):
             full.set_shard_split(r, world)
             ctx.split_stage1(full, None, send[r].data_ptr())
-        recv = _virtual_all_to_all(send, world)
+        recv = _virtual_all_to_all(send, world, ctx)
         for r in range(world):
             full.set_shard_split(r, world)
             ctx.split_stage2(full, recv[r].data_ptr(), send[r].data_ptr())
-        recv = _virtual_all_to_all(send, world)
+        recv = _virtual_all_to_all(send, world, ctx)
         parts = []
         for r in range(world):
             full.set_shard_split(r, world)
@@ -476,11 +476,17 @@ def test_set_shard_on_resident_key(ctx, zk):
 
 
 # ---- the H-scalar chain split over the ranks too (SURVEY.md 8e rows NTT / buildABC / joinABC) --------------
-def _virtual_all_to_all(send, world):
-    """send[src][poly][M*32] -> recv[dst][poly][...]: dst receives chunk dst of every src, ordered by src --
-    what dist.all_to_all_single does per polynomial, for `world` virtual ranks living on one GPU."""
+def _virtual_all_to_all(send, world, ctx=None):
+    """send[src] = one rank's exchange buffer, laid out [dst][poly][Q*32] -> recv[dst] = [src][poly][Q*32]: what ONE
+    dist.all_to_all_single over the whole buffer does, for `world` virtual ranks living on one GPU. The stages only
+    enqueue on the library's stream, the permutation runs on torch's: synchronise on both sides."""
+    import torch
+    if ctx is not None:
+        ctx.synchronize()
     w, three, mb = send.shape
-    return send.view(w, three, world, mb // world).permute(2, 1, 0, 3).contiguous().view(w, three, mb)
+    out = send.view(w, world, three * mb // world).permute(1, 0, 2).contiguous().view(w, three, mb)
+    torch.cuda.synchronize()
+    return out
 
 
 def _split_chain_partials(ctx, keys, world, domain, d_witness=None):
@@ -489,10 +495,10 @@ def _split_chain_partials(ctx, keys, world, domain, d_witness=None):
     send = torch.zeros((world, 3, mb), dtype=torch.uint8, device="cuda")
     for r in range(world):
         ctx.split_stage1(keys[r], d_witness, send[r].data_ptr())
-    recv = _virtual_all_to_all(send, world)
+    recv = _virtual_all_to_all(send, world, ctx)
     for r in range(world):
         ctx.split_stage2(keys[r], recv[r].data_ptr(), send[r].data_ptr())
-    recv = _virtual_all_to_all(send, world)
+    recv = _virtual_all_to_all(send, world, ctx)
     for r in range(world):
         ctx.split_stage3(keys[r], recv[r].data_ptr())
     torch.cuda.synchronize()
@@ -572,11 +578,11 @@ def test_set_shard_split_on_resident_key(ctx, zk, log_domain, world):
         for r in range(world):
             circ.key.set_shard_split(r, world)
             ctx.split_stage1(circ.key, wptr, send[r].data_ptr())
-        recv = _virtual_all_to_all(send, world)
+        recv = _virtual_all_to_all(send, world, ctx)
         for r in range(world):
             circ.key.set_shard_split(r, world)
             ctx.split_stage2(circ.key, recv[r].data_ptr(), send[r].data_ptr())
-        recv = _virtual_all_to_all(send, world)
+        recv = _virtual_all_to_all(send, world, ctx)
         parts = []
         for r in range(world):
             circ.key.set_shard_split(r, world)
@@ -642,10 +648,10 @@ def test_prove_degenerate_witness(ctx, zk, monkeypatch):
 
 
 # ---- the real multi-process path: two ranks sharing this box's GPU, gloo collectives (rehearsal mode) ----------
-@pytest.mark.parametrize("extra", [[], ["--replicated-chain"]])
-def test_two_process_sharded_prove_rehearsal(extra):
-    """bench.py's N = 2 prove exactly as the driver launches it (torch.distributed.run, one process per rank),
-    except that both ranks use the one GPU and the exchanges go through the host (ZKPOA_BENCH_REHEARSE=1):
+@pytest.mark.parametrize("nproc,extra", [(2, []), (2, ["--replicated-chain"]), (4, [])])
+def test_multi_process_sharded_prove_rehearsal(nproc, extra):
+    """bench.py's N = 2 / N = 4 prove exactly as the driver launches it (torch.distributed.run, one process per
+    rank), except that the ranks share the one GPU and the exchanges go through the host (ZKPOA_BENCH_REHEARSE=1):
     split shards per process, the three stages around two all-to-alls (or the replicated chain), all-gather of
     the partial points, host assembly -- bench.py itself checks the proof against the known discrete logs."""
     import socket
@@ -656,13 +662,13 @@ def test_two_process_sharded_prove_rehearsal(extra):
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZKPOA_BENCH_REHEARSE="1")
-    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                         "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "prove_2p16"] + extra,
+                         "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--workload", "prove_2p16"] + extra,
                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert rc.returncode == 0, rc.stderr[-2000:]
     line = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["metric"] == "Groth16 proofs/sec"
+    assert line["n_gpus"] == nproc and line["metric"] == "Groth16 proofs/sec"
     assert ("replicated" if extra else "split") in line["config"]["parallelism"]
     assert "REHEARSAL" in line["data"]
 

@@ -152,8 +152,7 @@ def _split_worker(rank, world, port, q):
     _, w = g16.read_wtns(g["witness.wtns"])
     assert sharding.split_chain_supported(world, zkey.domainSize)
     model = SplitRank(zkey, w, rank, world)
-    a = torch.zeros((3, zkey.domainSize // world * 32), dtype=torch.uint8)
-    b = torch.zeros_like(a)
+    a, b = sharding.exchange_buffers(zkey.domainSize, world, torch.device("cpu"))
     sharding.split_h_chain(model.stage1, model.stage2, model.stage3, a, b, dist)
     q.put((rank, model.h, g16.h_scalars(zkey, w)[rank::world]))
     dist.barrier()

@@ -41,6 +41,7 @@ EXPORTS = [
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
     "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
+    "zkpoa_context_stream", "zkpoa_context_synchronize",
     "zkpoa_msm_table_build", "zkpoa_msm_table_free", "zkpoa_msm_table_info", "zkpoa_msm_table_run_lane",
 ]
 
@@ -72,6 +73,9 @@ def lib():
         L.zkpoa_context_create.argtypes = [ctypes.c_int, c_void_pp, ctypes.c_char_p, ctypes.c_ulong]
         L.zkpoa_context_destroy.argtypes = [ctypes.c_void_p]
         L.zkpoa_context_destroy.restype = None
+        L.zkpoa_context_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.zkpoa_context_stream.restype = ctypes.c_void_p
+        L.zkpoa_context_synchronize.argtypes = [ctypes.c_void_p]
         L.zkpoa_last_error.argtypes = [ctypes.c_void_p]
         L.zkpoa_last_error.restype = ctypes.c_char_p
         L.zkpoa_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -194,6 +198,15 @@ class Context:
     def _check(self, rc, what):
         if rc != PROVER_OK:
             raise ZkpoaError("%s failed (%d): %s" % (what, rc, lib().zkpoa_last_error(self._h).decode()))
+
+    def stream(self, lane=0):
+        """The HIP stream of a lane as an integer handle (wrap with torch.cuda.ExternalStream to order torch work /
+        RCCL collectives with the library's kernels without host synchronisation)."""
+        return int(lib().zkpoa_context_stream(self._h, lane) or 0)
+
+    def synchronize(self):
+        """Wait for lane 0's stream (the split-chain stages only enqueue)."""
+        self._check(lib().zkpoa_context_synchronize(self._h), "zkpoa_context_synchronize")
 
     def set_option(self, key, value):
         self._check(lib().zkpoa_set_option(self._h, key.encode(), int(value)), "zkpoa_set_option")

@@ -42,6 +42,23 @@ static __global__ __launch_bounds__(256) void range_check_kernel(const void* __r
   if (!bw) atomicOr(flag, 1u);   // no borrow: value >= P
 }
 
+// Split chain: the stages compute on [polynomial][M] arrays, the exchange buffers are laid out
+// [destination rank][polynomial][Q] (Q = M / G) so that ONE all-to-all with equal splits moves all three polynomials.
+// pack: work[x][h * Q + pl] -> xbuf[(h * 3 + x) * Q + pl]; unpack is the inverse. One thread per 16-byte half element.
+template <bool PACK>
+static __global__ __launch_bounds__(256) void split_pack_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                                uint32_t M, uint32_t Q) {
+  uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= (uint64_t)6 * M) return;
+  const uint32_t half = (uint32_t)(t & 1u);
+  const uint64_t e = t >> 1;                       // element in [3][M] order
+  const uint32_t x = (uint32_t)(e / M), p = (uint32_t)(e % M);
+  const uint32_t h = p / Q, pl = p % Q;
+  const uint64_t xe = ((uint64_t)h * 3u + x) * Q + pl;   // element in [G][3][Q] order
+  if (PACK) out[2 * xe + half] = in[2 * e + half];
+  else out[2 * e + half] = in[2 * xe + half];
+}
+
 constexpr uint32_t kAbcSkip = 0xffffffffu;   // rank of a record that belongs to another rank's constraint rows
 
 // pass 1: validate + histogram rows, remember the rank inside the row. err[0] != 0 on bad records.

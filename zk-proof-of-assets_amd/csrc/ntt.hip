@@ -30,8 +30,9 @@ void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool 
 void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
   engine(ctx)->dit(st, d_data, k, inverse);
 }
-void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h) {
-  engine(ctx)->split_mid(st, in, out, k, G, h);
+void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h,
+                   uint32_t rank_stride) {
+  engine(ctx)->split_mid(st, in, out, k, G, h, rank_stride);
 }
 void ntt_release(zkpoa_context* ctx) {
   if (ctx->ntt) {

@@ -184,9 +184,12 @@ struct SplitRoots {
   Fr fwd[8];   // (w^M)^e
 };
 
+// in / out: rank g's (resp. i2's) Q slots start at element g * rank_stride (exchange buffers are laid out
+// [rank][polynomial][Q], so rank_stride = 3 Q and the caller offsets the pointers by polynomial * Q).
 template <uint32_t G>
 static __global__ __launch_bounds__(256) void ntt_split_mid_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                                   uint32_t Q, uint32_t slot0, uint32_t logM,
+                                                                   uint32_t Q, uint32_t rank_stride, uint32_t slot0,
+                                                                   uint32_t logM,
                                                                    SplitRoots roots, const void* __restrict__ inv_hi,
                                                                    const void* __restrict__ inv_lo,
                                                                    const void* __restrict__ fwd_hi,
@@ -201,7 +204,7 @@ static __global__ __launch_bounds__(256) void ntt_split_mid_kernel(const void* _
   char* dst = reinterpret_cast<char*>(out);
   Fr v[G], a[G];
 #pragma unroll
-  for (uint32_t g = 0; g < G; g++) v[g] = load_field<Fr>(src + 32 * ((size_t)g * Q + pl));
+  for (uint32_t g = 0; g < G; g++) v[g] = load_field<Fr>(src + 32 * ((size_t)g * rank_stride + pl));
   {
     Fr t = tw_lookup(inv_hi, inv_lo, L, k1), pw = t;
 #pragma unroll
@@ -224,7 +227,7 @@ static __global__ __launch_bounds__(256) void ntt_split_mid_kernel(const void* _
 #pragma unroll
     for (uint32_t k2 = 1; k2 < G; k2++) acc = acc + a[k2] * roots.fwd[(k2 * i2) & (G - 1u)];
     if (i2) acc = acc * pw;
-    store_field(dst + 32 * ((size_t)i2 * Q + pl), acc);
+    store_field(dst + 32 * ((size_t)i2 * rank_stride + pl), acc);
     pw = pw * t;
   }
 }
@@ -416,8 +419,9 @@ struct NttEngine {
   }
 
   // the part of to_odd_coset between the two exchanges when the transform is split over G ranks
-  // (ntt_split_mid_kernel); k = log2 n of the whole domain, h = this rank, in/out: [G][M / G] elements.
-  void split_mid(hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h) {
+  // (ntt_split_mid_kernel); k = log2 n of the whole domain, h = this rank, in/out: G blocks of M / G elements,
+  // `rank_stride` elements apart.
+  void split_mid(hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h, uint32_t rank_stride) {
     uint32_t lg = 0;
     while ((1u << lg) < G) lg++;
     const uint32_t logM = k - lg, Q = (1u << logM) / G;
@@ -436,7 +440,7 @@ struct NttEngine {
     dim3 grid((Q + 255) / 256), block(256);
     const uint32_t Lc = (k + 1) / 2;
 #define ZK_SPLIT_MID(GG)                                                                                            \
-  hipLaunchKernelGGL((ntt_split_mid_kernel<GG>), grid, block, 0, st, in, out, Q, h * Q, logM, roots,                \
+  hipLaunchKernelGGL((ntt_split_mid_kernel<GG>), grid, block, 0, st, in, out, Q, rank_stride, h * Q, logM, roots,   \
                      (const void*)ti.hi, (const void*)ti.lo, (const void*)tf.hi, (const void*)tf.lo, ti.L,          \
                      (const void*)tc.first, (const void*)tc.second, Lc)
     if (G == 2) ZK_SPLIT_MID(2);

@@ -235,9 +235,8 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool loca
   const uint32_t lp = local_rows ? zk->split_log : 0u, part = local_rows ? zk->split_rank : 0u;
   const uint32_t rows = 2 * (zk->domain >> lp);
   const uint64_t n = zk->domain, m = zk->nVars;
-  // work area: the unsplit chain transforms A_T, B_T, C_T in place; a file-loaded split shard only keeps its
-  // n / G H scalars here (the transforms run in the caller's exchange buffers)
-  if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, local_rows ? (size_t)(n >> lp) * 32 : (size_t)3 * n * 32));
+  // work area: the chain transforms A_T, B_T, C_T in place (a split shard: its n / G rows of each)
+  if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * (n >> lp) * 32));
   if (!zk->d_witness) ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
   if (!zk->d_flag) ZK_HIP(hipMalloc(reinterpret_cast<void**>(&zk->d_flag), 64));
   DevBuf d_cnt((size_t)rows * 4), d_rank((size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4),
@@ -514,13 +513,16 @@ void h_chain(zkpoa_context* ctx, hipStream_t st, const uint32_t* row_ptr, const 
 }
 
 // ---- split chain: three local stages around two all-to-all exchanges the caller runs ----
-// Exchange buffers (caller's device memory, e.g. torch tensors handed to RCCL): 3 polynomials (A, B, C) x
-// M = domain / G elements x 32 B, polynomial-major. Between stage 1 and 2, and between 2 and 3, every
-// polynomial is exchanged with equal splits of Q = M / G elements (all_to_all_single semantics).
+// Exchange buffers (caller's device memory, e.g. torch tensors handed to RCCL): [G ranks][3 polynomials A, B, C]
+// [Q = M / G elements] x 32 B, M = domain / G. Chunk h (3 Q elements, contiguous) is what rank h receives from this
+// rank, so each exchange is ONE all_to_all_single with equal splits over the whole buffer. The stages compute in the
+// handle's own work area ([3][M]) and pack / unpack at the boundary. All three ENQUEUE on lane 0's stream and return
+// (zkpoa_context_stream): a caller that runs its collectives on that stream needs no host synchronisation between
+// stage and exchange; anyone else calls zkpoa_context_synchronize first.
 void split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
   hipStream_t st = ctx->dev.lanes[0].stream;
-  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log;
-  char* A = reinterpret_cast<char*>(d_x);
+  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log, Q = M >> zk->split_log;
+  char* A = reinterpret_cast<char*>(zk->d_abc);
   char* B = A + (size_t)M * 32;
   char* C = B + (size_t)M * 32;
   zk->h_ready = false;
@@ -536,32 +538,33 @@ void split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
                        zk->csr_local ? 0u : zk->split_log, zk->csr_local ? 0u : zk->split_rank, (void*)A, (void*)B,
                        (void*)C);
   for (char* X : {A, B, C}) ntt_dif(ctx, st, X, kM, true);
-  ZK_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL((split_pack_kernel<true>), dim3((uint32_t)(((uint64_t)6 * M + 255) / 256)), dim3(256), 0, st,
+                     (const uint4*)zk->d_abc, (uint4*)d_x, M, Q);
   ZK_HIP(hipGetLastError());
 }
 
 void split_stage2(zkpoa_context* ctx, const zkpoa_zkey* zk, const void* d_in, void* d_out) {
   hipStream_t st = ctx->dev.lanes[0].stream;
-  const size_t M = zk->domain >> zk->split_log;
-  for (int x = 0; x < 3; x++)
-    ntt_split_mid(ctx, st, reinterpret_cast<const char*>(d_in) + x * M * 32, reinterpret_cast<char*>(d_out) + x * M * 32,
-                  zk->power, zk->split_world, zk->split_rank);
-  ZK_HIP(hipStreamSynchronize(st));
+  const size_t M = zk->domain >> zk->split_log, Q = M >> zk->split_log;
+  for (int x = 0; x < 3; x++)   // polynomial x of every rank's block: offset x * Q, blocks 3 Q apart
+    ntt_split_mid(ctx, st, reinterpret_cast<const char*>(d_in) + x * Q * 32, reinterpret_cast<char*>(d_out) + x * Q * 32,
+                  zk->power, zk->split_world, zk->split_rank, (uint32_t)(3 * Q));
   ZK_HIP(hipGetLastError());
 }
 
-void split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
+void split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zk, const void* d_x) {
   hipStream_t st = ctx->dev.lanes[0].stream;
-  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log;
-  char* A = reinterpret_cast<char*>(d_x);
+  const uint32_t M = zk->domain >> zk->split_log, kM = zk->power - zk->split_log, Q = M >> zk->split_log;
+  char* A = reinterpret_cast<char*>(zk->d_abc);
   char* B = A + (size_t)M * 32;
   char* C = B + (size_t)M * 32;
+  hipLaunchKernelGGL((split_pack_kernel<false>), dim3((uint32_t)(((uint64_t)6 * M + 255) / 256)), dim3(256), 0, st,
+                     (const uint4*)d_x, (uint4*)zk->d_abc, M, Q);
   for (char* X : {A, B, C}) ntt_dit(ctx, st, X, kM, false);
   hipLaunchKernelGGL(abc_join_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const void*)A, (const void*)B,
                      (const void*)C, M, zk->d_abc);
-  ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
-  zk->h_ready = true;
+  zk->h_ready = true;   // in stream order: the H MSM of zkpoa_prove_partials_device runs on the same stream
 }
 
 HFr hfr_from_le(const uint8_t* le) { return HFr::from_bytes(le); }
@@ -702,6 +705,10 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   const bool split = zk->split_world > 1;
   if (split && !zk->h_ready)
     throw ProverError(PROVER_ERROR, "split chain: run zkpoa_split_stage1/2/3 for this witness before zkpoa_prove_partials");
+  if (ctx->ev_witness_set) {   // an asynchronous witness copy (zkpoa_split_stage1) must land before lanes 1-4 read it
+    for (int l = 1; l < 5; l++) ZK_HIP(hipStreamWaitEvent(ctx->dev.lanes[l].stream, ctx->ev_witness, 0));
+    ctx->ev_witness_set = false;
+  }
   const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
                          : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
   const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
@@ -1369,8 +1376,12 @@ extern "C" int zkpoa_split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zkey, co
     ZK_HIP(hipSetDevice(ctx->dev.device));
     if (zkey->split_world < 2) throw ProverError(PROVER_ERROR, "split chain: the key handle is not a split shard");
     hipStream_t st = ctx->dev.lanes[0].stream;
-    if (d_witness && d_witness != zkey->d_witness)
+    if (d_witness && d_witness != zkey->d_witness) {
       ZK_HIP(hipMemcpyAsync(zkey->d_witness, d_witness, (size_t)zkey->nVars * 32, hipMemcpyDeviceToDevice, st));
+      if (!ctx->ev_witness) ZK_HIP(hipEventCreateWithFlags(&ctx->ev_witness, hipEventDisableTiming));
+      ZK_HIP(hipEventRecord(ctx->ev_witness, st));   // the witness MSMs run on other lanes: they wait for this copy
+      ctx->ev_witness_set = true;
+    }
     split_stage1(ctx, zkey, d_exchange);
   }
   ZK_PROVER_CATCH(ctx)
@@ -1394,6 +1405,27 @@ extern "C" int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, vo
     ZK_HIP(hipSetDevice(ctx->dev.device));
     if (zkey->split_world < 2) throw ProverError(PROVER_ERROR, "split chain: the key handle is not a split shard");
     split_stage3(ctx, zkey, d_received);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" void* zkpoa_context_stream(zkpoa_context* ctx, int lane) {
+  if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes) return nullptr;
+  try {
+    if (lane) ctx->dev.wait_lanes();
+  } catch (const std::exception&) {
+    return nullptr;
+  }
+  return reinterpret_cast<void*>(ctx->dev.lanes[lane].stream);
+}
+
+extern "C" int zkpoa_context_synchronize(zkpoa_context* ctx) {
+  if (!ctx) return PROVER_ERROR;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));
+    ZK_HIP(hipGetLastError());
   }
   ZK_PROVER_CATCH(ctx)
   return PROVER_OK;

@@ -40,6 +40,7 @@ extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev.device);
   (void)hipDeviceSynchronize();
+  if (ctx->ev_witness) (void)hipEventDestroy(ctx->ev_witness);
   for (int i = 0; i < DeviceCtx::kLanes; i++) {
     if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);

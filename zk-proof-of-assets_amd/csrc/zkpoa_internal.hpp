@@ -23,6 +23,9 @@ struct zkpoa_context {
   int opt_msm_c = 0;
   long opt_msm_max_points = 0;   // 0 = default (2^27): larger MSMs run in chunks
   int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
+  // split chain: the witness copy of zkpoa_split_stage1 is enqueued on lane 0; the other lanes' MSMs wait for it
+  hipEvent_t ev_witness = nullptr;
+  bool ev_witness_set = false;
   hipEvent_t ev_a[zkpoa::DeviceCtx::kLanes] = {};
   hipEvent_t ev_b[zkpoa::DeviceCtx::kLanes] = {};
 };
@@ -86,7 +89,8 @@ void ntt_natural(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, b
 void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
 void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
 // H-scalar chain split over G ranks: the step between the two exchanges (ntt.hip.h, ntt_split_mid_kernel)
-void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h);
+void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h,
+                   uint32_t rank_stride);
 void ntt_release(zkpoa_context* ctx);
 }  // namespace zkpoa
 

@@ -11,7 +11,9 @@ The H-scalar chain (buildABC, 3 x ifft -> coset shift -> fft, joinABC) shards to
 every transform is a four-step NTT over world = G ranks with ONE all-to-all, i.e. two exchanges per
 polynomial for the whole chain, each rank sending n*32/G^2 bytes to every peer in a single hop (xGMI is
 point-to-point, so all 7 links carry their own pair concurrently; no ring). `split_h_chain` below runs the
-three local stages (C ABI zkpoa_split_stage1/2/3) around `dist.all_to_all_single`.
+three local stages (C ABI zkpoa_split_stage1/2/3) around ONE `dist.all_to_all_single` per exchange (the exchange
+buffers are laid out [rank][polynomial][slots], so all three polynomials travel in one collective), enqueued on the
+library's own stream: two collectives and no host synchronisation for the whole chain.
 """
 
 
@@ -72,42 +74,62 @@ def split_chain_supported(world, domain):
     return world in (2, 4, 8) and world * world <= domain
 
 
-def exchange(recv, send, dist=None, sync=None):
-    """One exchange of the split chain: for each of the 3 polynomials (dim 0 of the uint8 tensors, shape
-    [3, M*32]) an all-to-all with equal splits, so rank h receives slots [h*Q, (h+1)*Q) of every rank's
-    buffer, ordered by source rank. `sync` (e.g. torch.cuda.synchronize) runs after the collectives so the
-    next stage, which runs on the library's own stream, sees the data."""
+def exchange(recv, send, dist=None):
+    """One exchange of the split chain: ONE all-to-all with equal splits over the whole buffer. The buffers are laid
+    out [rank][polynomial A, B, C][Q * 32 bytes] (include/zkpoa_prover.h), so chunk h of `send` is everything rank h
+    needs from this rank and `recv` ends up ordered by source rank. Runs on torch's CURRENT stream: inside
+    `library_stream(ctx)` that is the stream the stages were enqueued on, and RCCL's stream is ordered against it with
+    events (no host synchronisation)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         recv.copy_(send)
     elif send.is_cuda and dist.get_backend() == "gloo":
         # rehearsal only (ranks sharing a GPU, CPU process group): stage the exchange through the host
         hs = send.cpu()
         hr = hs.new_empty(hs.shape)
-        for x in range(hs.shape[0]):
-            dist.all_to_all_single(hr[x], hs[x])
+        dist.all_to_all_single(hr.view(-1), hs.view(-1))
         recv.copy_(hr)
     else:
-        for x in range(send.shape[0]):
-            dist.all_to_all_single(recv[x], send[x])
-    if sync is not None:
-        sync()
+        dist.all_to_all_single(recv.view(-1), send.view(-1))
 
 
-def split_h_chain(stage1, stage2, stage3, buf_a, buf_b, dist=None, sync=None):
+class library_stream:
+    """Context manager: makes the library's lane-0 HIP stream torch's current stream, so that the split-chain stages
+    (enqueued there by the C ABI) and the collectives between them are ordered on the device. For CPU buffers (the
+    gloo tests over the big-int stage model) it does nothing."""
+
+    def __init__(self, ctx, device=None):
+        self._cm = None
+        if ctx is not None and device is not None and getattr(device, "type", "cpu") == "cuda":
+            import torch
+            self._cm = torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream(0), device=device))
+
+    def __enter__(self):
+        if self._cm is not None:
+            self._cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._cm is not None:
+            return self._cm.__exit__(*exc)
+        return False
+
+
+def split_h_chain(stage1, stage2, stage3, buf_a, buf_b, dist=None):
     """The three local stages around the two exchanges. stageN take the buffers as the C ABI does:
-    stage1(out=buf_a); exchange a->b; stage2(in=buf_b, out=buf_a); exchange a->b; stage3(inout=buf_b).
-    After it the rank's H scalars live on its key handle (zkpoa_split_stage3)."""
+    stage1(out=buf_a); exchange a->b; stage2(in=buf_b, out=buf_a); exchange a->b; stage3(in=buf_b).
+    After it the rank's H scalars live on its key handle (zkpoa_split_stage3). Per proof: 2 collectives, no host
+    synchronisation (call it inside library_stream(ctx))."""
     stage1(buf_a)
-    exchange(buf_b, buf_a, dist, sync)
+    exchange(buf_b, buf_a, dist)
     stage2(buf_b, buf_a)
-    exchange(buf_b, buf_a, dist, sync)
+    exchange(buf_b, buf_a, dist)
     stage3(buf_b)
 
 
 def exchange_buffers(domain, world, device):
-    """The two exchange buffers of the split chain: 3 polynomials x (domain / world) x 32 B each."""
+    """The two exchange buffers of the split chain: [world ranks][3 polynomials][Q = domain / world^2 elements x 32 B]."""
     import torch
-    buf_a = torch.empty((3, domain // world * 32), dtype=torch.uint8, device=device)
+    buf_a = torch.empty((world, 3, domain // world // world * 32), dtype=torch.uint8, device=device)
     return buf_a, torch.empty_like(buf_a)
 
 
@@ -115,11 +137,12 @@ def sharded_prove_split(ctx, key, d_witness, header_points, sum_partials, assemb
     """One Groth16 proof over world GPUs with the H-scalar chain split as well (key: a split shard handle,
     load_zkey_shard_split / set_shard_split; d_witness: device pointer or None for the witness already on the
     handle; buffers: exchange_buffers(...) kept across proofs). Returns proof_points[256], identical on every rank."""
-    import torch
     buf_a, buf_b = buffers if buffers is not None else exchange_buffers(key.info()[2], dist.get_world_size(), device)
-    sync = torch.cuda.synchronize if buf_a.is_cuda else None
-    split_h_chain(lambda a: ctx.split_stage1(key, d_witness, a.data_ptr()),
-                  lambda b, a: ctx.split_stage2(key, b.data_ptr(), a.data_ptr()),
-                  lambda b: ctx.split_stage3(key, b.data_ptr()), buf_a, buf_b, dist, sync)
+    with library_stream(ctx, buf_a.device):
+        split_h_chain(lambda a: ctx.split_stage1(key, d_witness, a.data_ptr()),
+                      lambda b, a: ctx.split_stage2(key, b.data_ptr(), a.data_ptr()),
+                      lambda b: ctx.split_stage3(key, b.data_ptr()), buf_a, buf_b, dist)
+    # the witness MSMs (other lanes) start now and overlap whatever of the chain is still in flight on lane 0; the H
+    # MSM follows stage 3 in stream order. Host synchronisations per proof: the MSMs' own read-backs + this all-gather.
     return sharded_prove(lambda: ctx.prove_partials_device(key, None), header_points, sum_partials, assemble, r, s,
                          dist, device)
