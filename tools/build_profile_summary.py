@@ -1,16 +1,18 @@
-"""Turns gpurun_out/profiles_r01/* (tools/collect_profiles.sh) into the files committed under profiles/."""
+"""Turns gpurun_out/profiles_<round>/* (tools/collect_profiles.sh) into the files committed under profiles/.
+usage: python tools/build_profile_summary.py [round, default r02]"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "profiles_r01")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", "profiles_" + RND)
 DST = os.path.join(ROOT, "profiles")
-for old in glob.glob(os.path.join(DST, "r01_*")):
+for old in glob.glob(os.path.join(DST, RND + "_*")):
     os.remove(old)
 
 def only(pattern):
     """exactly one match: gpurun merges into an existing gpurun_out/, so stale runs must be deleted first"""
     fs = glob.glob(pattern)
     if len(fs) != 1:
-        sys.exit("expected one file for %s, found %d: rm -rf gpurun_out/profiles_r01 and collect again" % (pattern, len(fs)))
+        sys.exit("expected one file for %s, found %d: rm -rf gpurun_out/profiles_<round> and collect again" % (pattern, len(fs)))
     return fs[0]
 
 
@@ -23,10 +25,12 @@ def last_json_line(path):
 for f in glob.glob(os.path.join(SRC, "bench_*.json.log")):
     line = last_json_line(f)
     if line:
-        open(os.path.join(DST, "r01_" + os.path.basename(f)), "w").write(line + "\n")
-for tag in ("default", "inflight1", "msm26", "prove25"):
-    shutil.copy(only(os.path.join(SRC, "stats_" + tag, "*", "*kernel_stats.csv")),
-                os.path.join(DST, "r01_kernel_stats_%s.csv" % tag))
+        open(os.path.join(DST, RND + "_" + os.path.basename(f)), "w").write(line + "\n")
+for d in sorted(glob.glob(os.path.join(SRC, "stats_*"))):
+    if not os.path.isdir(d):
+        continue
+    tag = os.path.basename(d)[len("stats_"):]
+    shutil.copy(only(os.path.join(d, "*", "*kernel_stats.csv")), os.path.join(DST, "%s_kernel_stats_%s.csv" % (RND, tag)))
 
 def summarize(tag, counter):
     f = only(os.path.join(SRC, "pmc_%s_%s" % (tag, counter), "*", "*counter_collection.csv"))
@@ -47,7 +51,10 @@ out["calibration"] = {
     "expected_read_KiB": rd, "FETCH_SIZE_KiB": f[k][1], "fetch_ratio": f[k][1] / rd,
     "expected_write_KiB": wr, "WRITE_SIZE_KiB": w[k][1], "write_ratio": w[k][1] / wr,
     "conclusion": "for this access pattern both counters read the true bytes within 5 %: no x2 correction applied"}
-for tag, name in (("msm20", "msm_g1_2p20"), ("msm26", "msm_g1_2p26")):
+for tag, name in (("msm20", "msm_g1_2p20"), ("msm20fb", "msm_g1_2p20_fixed_base"), ("msm26", "msm_g1_2p26"),
+                  ("msm26fb", "msm_g1_2p26_fixed_base")):
+    if not glob.glob(os.path.join(SRC, "pmc_%s_FETCH_SIZE" % tag)):
+        continue
     f, w = summarize(tag, "FETCH_SIZE"), summarize(tag, "WRITE_SIZE")
     ks = {}
     for kk in f:
@@ -62,9 +69,9 @@ for tag, name in (("msm20", "msm_g1_2p20"), ("msm26", "msm_g1_2p26")):
                          "WRITE_SIZE_KiB": w.get(kk, (0, 0))[1],
                          "bytes_per_launch": (fc * f[kk][1] + w.get(kk, (0, 0))[1]) * 1024}
     out["workloads"][name] = ks
-json.dump(out, open(os.path.join(DST, "r01_pmc_hbm_traffic.json"), "w"), indent=1)
-for extra in ("pcie_inclusive2.log",):
+json.dump(out, open(os.path.join(DST, RND + "_pmc_hbm_traffic.json"), "w"), indent=1)
+for extra in ("pcie_inclusive_%s.log" % RND,):
     p = os.path.join(ROOT, "gpurun_out", extra)
     if os.path.exists(p):
-        shutil.copy(p, os.path.join(DST, "r01_pcie_inclusive.log"))
+        shutil.copy(p, os.path.join(DST, RND + "_pcie_inclusive.log"))
 print(sorted(os.listdir(DST)))
