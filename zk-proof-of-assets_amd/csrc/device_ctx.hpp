@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
+#include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <stdexcept>
@@ -97,6 +98,12 @@ struct DeviceCtx {
   std::thread bg_;
   std::mutex bg_mutex_;
   std::exception_ptr bg_err_;
+  // A stream of its own for host -> HBM copies that run WHILE lanes compute (one-shot proves overlap the zkey upload
+  // with the MSMs). First thing the background thread creates; copy_stream_wait() blocks until it exists.
+  hipStream_t copy_stream = nullptr;
+  std::mutex copy_mutex_;
+  std::condition_variable copy_cv_;
+  bool copy_done_ = false;
 
   void init(int dev) {
     const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
@@ -125,15 +132,33 @@ struct DeviceCtx {
     bg_ = std::thread([this] {
       try {
         ZK_HIP(hipSetDevice(device));
+        hipError_t ce = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        if (ce != hipSuccess) copy_stream = nullptr;
+        {
+          std::lock_guard<std::mutex> lk(copy_mutex_);
+          copy_done_ = true;
+        }
+        copy_cv_.notify_all();
         for (int i = 1; i < kLanes; i++) lanes[i].init(i == 3 ? 1 : 0);
       } catch (...) {
         bg_err_ = std::current_exception();
+        {
+          std::lock_guard<std::mutex> lk(copy_mutex_);
+          copy_done_ = true;
+        }
+        copy_cv_.notify_all();
       }
     });
     if (verbose)
       fprintf(stderr, "zkpoa: HIP runtime up in %.1f ms, first lane in %.1f ms (the other %d in the background)\n",
               t1 - t0, now_ms() - t1, kLanes - 1);
     ok = true;
+  }
+  // the copy stream (nullptr when it could not be created: callers then copy on lane 0's stream)
+  hipStream_t copy_stream_wait() {
+    std::unique_lock<std::mutex> lk(copy_mutex_);
+    copy_cv_.wait(lk, [this] { return copy_done_; });
+    return copy_stream;
   }
   // every lane other than 0 may only be used after this (cheap once the background thread has been joined)
   void wait_lanes() {
@@ -153,6 +178,8 @@ struct DeviceCtx {
     }
     (void)hipSetDevice(device);
     for (auto& l : lanes) l.destroy();
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
     ok = false;
   }
 };

@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <exception>
 #include <functional>
@@ -230,8 +231,8 @@ uint32_t build_long_list(hipStream_t st, const uint32_t* d_row_ptr, uint32_t row
 // CSR of the coefficient list by output row (2*c + m); d_recs = device copy of the 44-byte records.
 // Also allocates the A/B/C work area and the witness buffer. With split_log > 0 (split chain loaded from a
 // file) only the records of this rank's constraints are kept, rows renumbered c >> split_log.
-void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool local_rows = false) {
-  hipStream_t st = ctx->dev.lanes[0].stream;
+void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool local_rows = false, hipStream_t st_in = nullptr) {
+  hipStream_t st = st_in ? st_in : ctx->dev.lanes[0].stream;
   const uint32_t lp = local_rows ? zk->split_log : 0u, part = local_rows ? zk->split_rank : 0u;
   const uint32_t rows = 2 * (zk->domain >> lp);
   const uint64_t n = zk->domain, m = zk->nVars;
@@ -304,8 +305,8 @@ void queries_set_slice(zkpoa_zkey* zk) {
 
 // Compact the resident range [wbase, wbase + wres) of a query (d1: G1 section, d2: its G2 twin or null) once per key.
 void query_compact(zkpoa_context* ctx, zkpoa_zkey* zk, zkpoa_zkey::CompactQuery& q, const void* d1, const void* d2,
-                   uint64_t wres) {
-  hipStream_t st = ctx->dev.lanes[0].stream;
+                   uint64_t wres, hipStream_t st_in = nullptr) {
+  hipStream_t st = st_in ? st_in : ctx->dev.lanes[0].stream;
   const uint32_t n = (uint32_t)wres;
   DevBuf keep(((size_t)n + 1) * 4), bs(((size_t)n / kScanTile + 2) * 4), misc(64);
   ZK_HIP(hipMalloc(reinterpret_cast<void**>(&q.pos), ((size_t)n + 1) * 4));
@@ -349,8 +350,13 @@ void queries_compact(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t wres) {
   }
 }
 
-zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
-                           uint64_t world = 1, bool split = false) {
+// the five point sections and the coefficient section of a parsed zkey
+struct ZkeySections {
+  Section s4, s5, s6, s7, s8, s9;
+};
+
+// container + header validation; fills the handle's scalar fields, header points and verification key
+std::unique_ptr<zkpoa_zkey> zkey_parse(const uint8_t* buf, uint64_t size, ZkeySections& out) {
   Sections secs = parse_binfile(buf, size, "zkey", 2);
   const Section& s1 = need(secs, 1, "1 (protocol)");
   if (s1.len < 4 || rd_u32(s1.p) != 1) throw ProverError(PROVER_ERROR, "zkey file is not groth16");
@@ -395,20 +401,29 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
       memcpy(v + 448, it3->second.p, it3->second.len);
     }
   }
-
-  const Section& s4 = need(secs, 4, "4 (coefficients)");
-  if (s4.len < 4) throw ProverError(PROVER_ERROR, "zkey coefficient section too short");
-  zk->nCoefs = rd_u32(s4.p);
-  if (s4.len != 4 + zk->nCoefs * 44) throw ProverError(PROVER_ERROR, "zkey coefficient section has the wrong size");
-  const Section& s5 = need(secs, 5, "5 (A points)");
-  const Section& s6 = need(secs, 6, "6 (B1 points)");
-  const Section& s7 = need(secs, 7, "7 (B2 points)");
-  const Section& s8 = need(secs, 8, "8 (C points)");
-  const Section& s9 = need(secs, 9, "9 (H points)");
+  out.s4 = need(secs, 4, "4 (coefficients)");
+  if (out.s4.len < 4) throw ProverError(PROVER_ERROR, "zkey coefficient section too short");
+  zk->nCoefs = rd_u32(out.s4.p);
+  if (out.s4.len != 4 + zk->nCoefs * 44) throw ProverError(PROVER_ERROR, "zkey coefficient section has the wrong size");
+  out.s5 = need(secs, 5, "5 (A points)");
+  out.s6 = need(secs, 6, "6 (B1 points)");
+  out.s7 = need(secs, 7, "7 (B2 points)");
+  out.s8 = need(secs, 8, "8 (C points)");
+  out.s9 = need(secs, 9, "9 (H points)");
   const uint64_t m = zk->nVars, n = zk->domain;
-  if (s5.len != m * 64 || s6.len != m * 64 || s7.len != m * 128 || s8.len != (m - zk->nPublic - 1) * 64 ||
-      s9.len != n * 64)
+  if (out.s5.len != m * 64 || out.s6.len != m * 64 || out.s7.len != m * 128 ||
+      out.s8.len != (m - zk->nPublic - 1) * 64 || out.s9.len != n * 64)
     throw ProverError(PROVER_ERROR, "zkey point section has the wrong size");
+  return zk;
+}
+
+zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
+                           uint64_t world = 1, bool split = false) {
+  ZkeySections zs;
+  std::unique_ptr<zkpoa_zkey> zk = zkey_parse(buf, size, zs);
+  const Section &s4 = zs.s4, &s5 = zs.s5, &s6 = zs.s6, &s7 = zs.s7, &s8 = zs.s8, &s9 = zs.s9;
+  const uint64_t m = zk->nVars, n = zk->domain;
+  (void)m;
 
   if (world == 0 || rank >= world) throw ProverError(PROVER_ERROR, "zkey shard: rank/world out of range");
   zk->set_shard(rank, world);   // world == 1: the whole key
@@ -685,7 +700,14 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
 
 // Partial MSM results of this handle's shard: A(64) B1(64) B2(128) C(64) H(64). The witness is already
 // in zk->d_witness (device). The H-scalar chain runs in full on every rank (replicated).
-void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) {
+// Hooks of a one-shot prove that overlaps the key upload with the compute (load_prove_staged): each stage of
+// prove_partials first waits for the sections it needs and finishes their key-side preparation on its own lane.
+struct Staging {
+  std::function<void()> prep_chain, prep_H, prep_A, prep_B, prep_C;
+  std::vector<void*> sinks[5];   // temporaries parked until the proof is done (hipFree waits for the whole device)
+};
+
+void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], Staging* stg = nullptr) {
   auto t0 = std::chrono::steady_clock::now();
   ctx->dev.wait_lanes();
   Lane& l0 = ctx->dev.lanes[0];
@@ -697,11 +719,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   std::exception_ptr errs[4];
   float msm_ms[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   const char* wit = reinterpret_cast<const char*>(zk->d_witness);
-  // A, B1 and B2 run over the compacted queries (points at infinity dropped at key load) and gathered scalars
-  const char* pA = reinterpret_cast<const char*>(zk->qA.g1) + zk->qA.lo * 64;
-  const char* pB1 = reinterpret_cast<const char*>(zk->qB.g1) + zk->qB.lo * 64;
-  const char* pB2 = reinterpret_cast<const char*>(zk->qB.g2) + zk->qB.lo * 128;
-  const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
+  // A, B1 and B2 run over the compacted queries (points at infinity dropped at key load) and gathered scalars; the
+  // pointers are taken inside the stages (a staged prove builds the compacted queries there)
   const bool split = zk->split_world > 1;
   if (split && !zk->h_ready)
     throw ProverError(PROVER_ERROR, "split chain: run zkpoa_split_stage1/2/3 for this witness before zkpoa_prove_partials");
@@ -709,13 +728,12 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
     for (int l = 1; l < 5; l++) ZK_HIP(hipStreamWaitEvent(ctx->dev.lanes[l].stream, ctx->ev_witness, 0));
     ctx->ev_witness_set = false;
   }
-  const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
-                         : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
   const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
   auto guarded = [&](int slot, std::function<void()> fn) {
     return std::thread([&, slot, fn] {
       try {
         ZK_HIP(hipSetDevice(ctx->dev.device));
+        if (stg) deferred_free_sink() = &stg->sinks[slot];
         fn();
       } catch (...) {
         errs[slot] = std::current_exception();
@@ -737,25 +755,30 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   // are solo times and their sum / the overlapped wall time says how much the five lanes gain (bench.py).
   const bool serial = ctx->opt_prove_serial != 0;
   // fixed-base tables apply when the MSM covers the whole array the table was built from
-  const MsmTable* useA = (zk->tA && zk->qA.lo == 0 && zk->qA.cnt == zk->qA.res) ? zk->tA : nullptr;
-  const bool useB = zk->tB1 && zk->tB2 && zk->qB.lo == 0 && zk->qB.cnt == zk->qB.res;
-  const MsmTable* useC = (zk->tC && zk->clo == zk->cbase && !split_c_partial(zk)) ? zk->tC : nullptr;
-  const MsmTable* useH = (!split && zk->tH && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr;
   std::thread tA = guarded(0, [&] {
+    if (stg && stg->prep_A) stg->prep_A();
+    const MsmTable* useA = (zk->tA && zk->qA.lo == 0 && zk->qA.cnt == zk->qA.res) ? zk->tA : nullptr;
+    const char* pA = reinterpret_cast<const char*>(zk->qA.g1) + zk->qA.lo * 64;
     gather(1, zk->qA);
     msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1], useA);
   });
   if (serial) tA.join();
   // (a B query beyond the 32-bit entry index of one sort cannot share it: two chunked MSMs instead)
   const uint64_t sort_limit = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
-  const bool share_b = zk->qB.cnt <= sort_limit;
-  uint64_t tb_info[4] = {0, 0, 0, 0};
-  if (useB) msm_table_info(zk->tB1, tb_info);
-  const int table_c_b = useB && share_b ? (int)tb_info[1] : 0;
+  bool share_b = false;      // set by the B1 stage, read by the B2 stage after the sort has been published
+  int table_c_b = 0;
   float sort_b_ms = 0;   // the shared sort of the B query (host clock: the call returns with its stream synchronised)
   std::thread tB1 = guarded(1, [&] {
     MsmSorted* sr = nullptr;
+    const char* pB1 = nullptr;
     try {
+      if (stg && stg->prep_B) stg->prep_B();
+      const bool useB = zk->tB1 && zk->tB2 && zk->qB.lo == 0 && zk->qB.cnt == zk->qB.res;
+      share_b = zk->qB.cnt <= sort_limit;
+      uint64_t tb_info[4] = {0, 0, 0, 0};
+      if (useB) msm_table_info(zk->tB1, tb_info);
+      table_c_b = useB && share_b ? (int)tb_info[1] : 0;
+      pB1 = reinterpret_cast<const char*>(zk->qB.g1) + zk->qB.lo * 64;
       gather(2, zk->qB);
       auto ts0 = std::chrono::steady_clock::now();
       if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
@@ -773,16 +796,24 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   if (serial) tB1.join();
   std::thread tB2 = guarded(2, [&] {
     const MsmSorted* sr = sorted_ready.get();
+    const char* pB2 = reinterpret_cast<const char*>(zk->qB.g2) + zk->qB.lo * 128;
     if (share_b) msm_accum_g2(ctx, 3, sr, false, table_c_b ? msm_table_data(zk->tB2) : pB2, outB2, msm_ms[3]);
     else msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
   });
   if (serial) tB2.join();
-  std::thread tC = guarded(3, [&] { msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC); });
+  std::thread tC = guarded(3, [&] {
+    if (stg && stg->prep_C) stg->prep_C();
+    const MsmTable* useC = (zk->tC && zk->clo == zk->cbase && !split_c_partial(zk)) ? zk->tC : nullptr;
+    const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
+    msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC);
+  });
   if (serial) tC.join();
 
   std::exception_ptr main_err;
   uint32_t witness_bad = 0;
   try {
+    if (stg) deferred_free_sink() = &stg->sinks[4];
+    if (stg && stg->prep_chain) stg->prep_chain();
     // witness values must be canonical (< r): one streaming pass on the chain's lane, flag read with the H MSM's results
     ZK_HIP(hipMemsetAsync(zk->d_flag, 0, 4, l0.stream));
     range_check<FrParams>(l0.stream, zk->d_witness, zk->nVars, zk->d_flag);
@@ -791,6 +822,10 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
       h_chain(ctx, l0.stream, zk->d_row_ptr, zk->d_sig, zk->d_vals, zk->d_long, zk->n_long, zk->d_witness, zk->domain,
               zk->power, zk->d_abc);
     ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
+    if (stg && stg->prep_H) stg->prep_H();
+    const MsmTable* useH = (!split && zk->tH && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr;
+    const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
+                           : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
     if (split) {
       // the three stages left this rank's H scalars (odd-coset indices = rank mod G) in d_abc[0 .. n/G)
       msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0]);
@@ -803,6 +838,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384]) 
   } catch (...) {
     main_err = std::current_exception();
   }
+  deferred_free_sink() = nullptr;
   if (!serial) {
     tA.join();
     tB1.join();
@@ -945,6 +981,136 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   selfcheck(ctx, zk, proof_points, w.values + 32);
 }
 
+// ---- one-shot prove with the key upload overlapped ------------------------------------------
+// A one-shot `prover` run spends most of its time moving the key over PCIe (1 GB for layer one, 21 GB for layer
+// three), and none of the compute needs the whole key: the H-scalar chain needs the witness and section 4, the H MSM
+// section 9, the B MSMs sections 6 + 7, A section 5, C section 8. So the sections go up on a stream of their own in
+// the order  witness, 4, 9, 6, 7, 5, 8  (the stage with the least work after its last byte arrives goes last) while
+// every stage of prove_partials starts as soon as its own inputs are resident and does the key-side preparation of
+// that section (CSR build, dropping the points at infinity, range checks) on its own lane. Wall time tends to
+// max(upload, compute) + the C MSM instead of upload + compute. Returns the loaded key (complete, reusable: the cache
+// keeps it) with `parts` = the five MSM results; nullptr when no copy stream could be created (caller: plain path).
+zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, const WtnsView& w, uint8_t parts[384]) {
+  hipStream_t cs = ctx->dev.copy_stream_wait();
+  if (!cs) return nullptr;
+  ZkeySections zs;
+  std::unique_ptr<zkpoa_zkey> zk = zkey_parse(buf, size, zs);
+  if (w.n != zk->nVars)
+    throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
+                                                         ", witness: " + std::to_string(w.n));
+  zk->set_full();
+  const uint64_t m = zk->nVars, n = zk->domain, nC = m - zk->nPublic - 1;
+  zkpoa_zkey* k = zk.get();
+  void* d_recs = nullptr;
+  uint32_t* d_cflag = nullptr;
+  enum { S_WIT, S_COEF, S_H, S_B1, S_B2, S_A, S_C, S_COUNT };
+  std::promise<void> ready[S_COUNT];
+  std::shared_future<void> have[S_COUNT];
+  for (int i = 0; i < S_COUNT; i++) have[i] = ready[i].get_future().share();
+  std::atomic<bool> cancel{false};
+  std::thread uploader;
+  Staging stg;
+  auto cleanup_temps = [&] {
+    (void)hipDeviceSynchronize();
+    for (auto& v : stg.sinks) {
+      for (void* p : v) (void)hipFree(p);
+      v.clear();
+    }
+    if (d_recs) (void)hipFree(d_recs);
+    if (d_cflag) (void)hipFree(d_cflag);
+    d_recs = nullptr;
+    d_cflag = nullptr;
+  };
+  try {
+    auto alloc = [](void** p, uint64_t bytes) { ZK_HIP(hipMalloc(p, bytes ? bytes : 1)); };
+    alloc(&k->d_witness, m * 32);
+    alloc(&d_recs, zk->nCoefs * 44);
+    alloc(&k->dH, n * 64);
+    alloc(&k->dB1, m * 64);
+    alloc(&k->dB2, m * 128);
+    alloc(&k->dA, m * 64);
+    alloc(&k->dC, nC * 64);
+    alloc(reinterpret_cast<void**>(&d_cflag), 64);
+    ZK_HIP(hipMemset(d_cflag, 0, 64));
+    ctx->dev.wait_lanes();
+    struct Item { int id; void* dst; const uint8_t* src; uint64_t bytes; };
+    const Item items[S_COUNT] = {
+        {S_WIT, k->d_witness, w.values, m * 32}, {S_COEF, d_recs, zs.s4.p + 4, zk->nCoefs * 44},
+        {S_H, k->dH, zs.s9.p, n * 64},           {S_B1, k->dB1, zs.s6.p, m * 64},
+        {S_B2, k->dB2, zs.s7.p, m * 128},        {S_A, k->dA, zs.s5.p, m * 64},
+        {S_C, k->dC, zs.s8.p, nC * 64}};
+    uploader = std::thread([&] {
+      int i = 0;
+      try {
+        ZK_HIP(hipSetDevice(ctx->dev.device));
+        for (; i < S_COUNT; i++) {
+          if (cancel.load()) throw ProverError(PROVER_ERROR, "upload cancelled");
+          if (items[i].bytes) {
+            if (items[i].bytes < (4u << 20)) {   // small: one asynchronous copy on the copy stream (no null-stream copy here)
+              ZK_HIP(hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, cs));
+              ZK_HIP(hipStreamSynchronize(cs));
+            } else {
+              ctx->uploader.upload(items[i].dst, items[i].src, items[i].bytes, ctx->dev.device, cs);
+            }
+          }
+          ready[items[i].id].set_value();
+        }
+      } catch (...) {
+        for (; i < S_COUNT; i++) ready[items[i].id].set_exception(std::current_exception());
+      }
+    });
+    Lane* L = ctx->dev.lanes;
+    stg.prep_chain = [&, k] {
+      have[S_WIT].get();
+      have[S_COEF].get();
+      build_csr(ctx, k, d_recs, false, L[0].stream);
+      ntt_prepare(ctx, L[0].stream, k->power);
+    };
+    stg.prep_H = [&, k] {
+      have[S_H].get();
+      range_check<FqParams>(L[0].stream, k->dH, n * 2, d_cflag);
+    };
+    stg.prep_A = [&, k] {
+      have[S_WIT].get();
+      have[S_A].get();
+      range_check<FqParams>(L[1].stream, k->dA, m * 2, d_cflag);
+      query_compact(ctx, k, k->qA, k->dA, nullptr, m, L[1].stream);
+    };
+    stg.prep_B = [&, k] {
+      have[S_WIT].get();
+      have[S_B1].get();
+      have[S_B2].get();
+      range_check<FqParams>(L[2].stream, k->dB1, m * 2, d_cflag);
+      range_check<FqParams>(L[2].stream, k->dB2, m * 4, d_cflag);
+      query_compact(ctx, k, k->qB, k->dB1, k->dB2, m, L[2].stream);
+    };
+    stg.prep_C = [&, k] {
+      have[S_WIT].get();
+      have[S_C].get();
+      range_check<FqParams>(L[4].stream, k->dC, nC * 2, d_cflag);
+    };
+    prove_partials(ctx, k, parts, &stg);
+    uploader.join();
+    uint32_t bad = 0;
+    ZK_HIP(hipDeviceSynchronize());
+    ZK_HIP(hipMemcpy(&bad, d_cflag, 4, hipMemcpyDeviceToHost));
+    if (bad) throw ProverError(PROVER_ERROR, "zkey point coordinate is not a field element (>= q)");
+    // the originals of the compacted queries are not read again
+    stg.sinks[4].push_back(k->dA);
+    stg.sinks[4].push_back(k->dB1);
+    stg.sinks[4].push_back(k->dB2);
+    k->dA = k->dB1 = k->dB2 = nullptr;
+    cleanup_temps();
+  } catch (...) {
+    cancel.store(true);
+    if (uploader.joinable()) uploader.join();
+    cleanup_temps();
+    zk->release();
+    throw;
+  }
+  return zk.release();
+}
+
 // ---- JSON (byte formats pinned by the reference's committed fixtures) --------
 std::string fq_dec(const uint8_t* le_mont) { return HFq::from_bytes(le_mont).to_dec(); }
 bool all_zero(const uint8_t* p, size_t n) {
@@ -1049,13 +1215,9 @@ zkpoa_context* process_context(std::string& err) {
   return g_ctx;
 }
 
-// prove with a resident key, JSON out; options from the environment (ZKPOA_R / ZKPOA_S / ZKPOA_JSON / ZKPOA_VERBOSE)
-int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
-                  unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
-                  unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, bool cache_hit) {
-  int rc = PROVER_OK;
-  uint8_t rb[32], sb[32];
-  const uint8_t *rp = nullptr, *sp = nullptr;
+// r, s from the environment (ZKPOA_R / ZKPOA_S, decimal; test use) -> pointers, or null for /dev/urandom
+void env_blinding(uint8_t rb[32], uint8_t sb[32], const uint8_t*& rp, const uint8_t*& sp) {
+  rp = sp = nullptr;
   if (getenv("ZKPOA_R") || getenv("ZKPOA_S")) {
     static bool warned = false;
     if (!warned) {
@@ -1072,12 +1234,16 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
     if (!parse_decimal_mod_r(e, sb)) throw ProverError(PROVER_ERROR, "ZKPOA_S is not a decimal number");
     sp = sb;
   }
+}
+
+// proof points + public values -> the two JSON texts (ZKPOA_JSON style) + the ZKPOA_VERBOSE phase line
+int emit_outputs(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t pts[256], const uint8_t* pub, char* proof_buffer,
+                 unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+                 unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, const char* how) {
+  int rc = PROVER_OK;
   int style = 0;
   if (const char* e = getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
-  uint8_t pts[256];
-  std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
-  prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
-  std::string pj = proof_json(pts, style), uj = public_json(pub.data(), zk->nPublic, style);
+  std::string pj = proof_json(pts, style), uj = public_json(pub, zk->nPublic, style);
   int r1 = emit(pj, proof_buffer, proof_size);
   int r2 = emit(uj, public_buffer, public_size);
   if (r1 != PROVER_OK || r2 != PROVER_OK) {
@@ -1088,10 +1254,58 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
     fprintf(stderr,
             "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
             "msm phase %.2f ms, prove %.2f ms, self-check %.2f ms\n",
-            zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, cache_hit ? "cached," : "load", load_ms,
+            zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, how, load_ms,
             load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5], ctx->ms[6]);
   }
   return rc;
+}
+
+// prove with a resident key, JSON out; options from the environment (ZKPOA_R / ZKPOA_S / ZKPOA_JSON / ZKPOA_VERBOSE)
+int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+                  unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+                  unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, bool cache_hit) {
+  uint8_t rb[32], sb[32];
+  const uint8_t *rp = nullptr, *sp = nullptr;
+  env_blinding(rb, sb, rp, sp);
+  uint8_t pts[256];
+  std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
+  prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
+  return emit_outputs(ctx, zk, pts, pub.data(), proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                      error_msg_maxsize, load_ms, zkey_size, cache_hit ? "cached," : "load");
+}
+
+// One-shot: load the key and prove, with the upload overlapped unless ZKPOA_OVERLAP=0. *out_zk <- the loaded key
+// (the caller frees or caches it). load_ms <- time to the end of the proof (load and prove are one phase here).
+int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns,
+                           uint64_t wtns_size, char* proof_buffer, unsigned long* proof_size, char* public_buffer,
+                           unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize,
+                           zkpoa_zkey** out_zk) {
+  *out_zk = nullptr;
+  const char* ov = getenv("ZKPOA_OVERLAP");
+  auto tl0 = std::chrono::steady_clock::now();
+  if (!ov || strcmp(ov, "0") != 0) {
+    WtnsView w = parse_wtns(wtns, wtns_size);
+    uint8_t rb[32], sb[32], parts[384], header[448], pts[256];
+    const uint8_t *rp = nullptr, *sp = nullptr;
+    env_blinding(rb, sb, rp, sp);
+    auto t0 = std::chrono::steady_clock::now();
+    zkpoa_zkey* zk = load_prove_staged(ctx, zkey, zkey_size, w, parts);
+    if (zk) {
+      *out_zk = zk;
+      zkey_header_bytes(zk, header);
+      prove_assemble(header, parts, rp, sp, pts);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ctx->ms[5] = (float)ms;
+      selfcheck(ctx, zk, pts, w.values + 32);
+      return emit_outputs(ctx, zk, pts, w.values + 32, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                          error_msg_maxsize, ms, zkey_size, "load overlapped with the prove:");
+    }
+  }
+  zkpoa_zkey* zk = zkey_load_impl(ctx, zkey, zkey_size);
+  *out_zk = zk;
+  const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
+  return prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                       error_msg_maxsize, load_ms, zkey_size, false);
 }
 
 int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
@@ -1108,11 +1322,8 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
   int rc = PROVER_OK;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
-    auto tl0 = std::chrono::steady_clock::now();
-    zk = zkey_load_impl(ctx, zkey, zkey_size);
-    const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
-    rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
-                       error_msg_maxsize, load_ms, zkey_size, false);
+    rc = load_and_prove_to_json(ctx, zkey, zkey_size, wtns, wtns_size, proof_buffer, proof_size, public_buffer,
+                                public_size, error_msg, error_msg_maxsize, &zk);
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
@@ -1187,7 +1398,7 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
   std::lock_guard<std::mutex> lk(g_prove_mutex);
   int rc = PROVER_OK;
   zkpoa_zkey* zk = nullptr;
-  bool owned = false, hit = false;
+  bool owned = false, hit = false, proved = false;
   double load_ms = 0;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
@@ -1210,14 +1421,20 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
             if (g_key_cache[i].last_use < g_key_cache[lru].last_use) lru = i;
           key_cache_drop(lru);
         }
+        // load and prove in one overlapped phase (the mapping must outlive it: the uploader streams from it)
         try {
-          zk = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
+                                      proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
+                                      &zk);
         } catch (const HipError&) {
           if (g_key_cache.empty()) throw;
           key_cache_clear();                          // probably out of HBM: retry with nothing else resident
           (void)hipGetLastError();
-          zk = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
+                                      proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
+                                      &zk);
         }
+        proved = true;
       } catch (...) {
         munmap(map, (size_t)sb.st_size);
         throw;
@@ -1243,8 +1460,9 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
         }
       }
     }
-    rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
-                       error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
+    if (!proved)
+      rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                         error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
     zk->proofs_done++;
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());

@@ -38,11 +38,20 @@ struct zkpoa_msm_table {   // C-ABI handle of a fixed-base table (zkpoa_msm_tabl
 namespace zkpoa {
 void set_err(char* buf, unsigned long cap, const std::string& msg);
 
+// hipFree waits for the whole device, copies in flight included. While a one-shot prove overlaps the key upload with
+// compute, temporaries are therefore parked in the calling thread's sink and freed after the proof.
+inline std::vector<void*>*& deferred_free_sink() {
+  static thread_local std::vector<void*>* sink = nullptr;
+  return sink;
+}
+
 struct DevBuf {  // RAII device allocation for the host-buffer entry points
   void* p = nullptr;
   explicit DevBuf(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 1)); }
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    if (deferred_free_sink()) deferred_free_sink()->push_back(p);
+    else (void)hipFree(p);
   }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
