@@ -1437,6 +1437,12 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
         proved = true;
       } catch (...) {
         munmap(map, (size_t)sb.st_size);
+        if (zk) {   // loaded, but the proof failed afterwards (self-check, output): not cached, not leaked
+          (void)hipDeviceSynchronize();
+          zk->release();
+          delete zk;
+          zk = nullptr;
+        }
         throw;
       }
       munmap(map, (size_t)sb.st_size);
