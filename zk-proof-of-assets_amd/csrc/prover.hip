@@ -990,7 +990,9 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
 // that section (CSR build, dropping the points at infinity, range checks) on its own lane. Wall time tends to
 // max(upload, compute) + the C MSM instead of upload + compute. Returns the loaded key (complete, reusable: the cache
 // keeps it) with `parts` = the five MSM results; nullptr when no copy stream could be created (caller: plain path).
-zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, const WtnsView& w, uint8_t parts[384]) {
+// zkey_fd >= 0: the file `buf` maps; the sections are then read with pread instead of through the mapping.
+zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, const WtnsView& w, uint8_t parts[384],
+                              int zkey_fd = -1) {
   hipStream_t cs = ctx->dev.copy_stream_wait();
   if (!cs) return nullptr;
   ZkeySections zs;
@@ -1050,7 +1052,9 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
               ZK_HIP(hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, cs));
               ZK_HIP(hipStreamSynchronize(cs));
             } else {
-              ctx->uploader.upload(items[i].dst, items[i].src, items[i].bytes, ctx->dev.device, cs);
+              const bool from_file = zkey_fd >= 0 && items[i].src >= buf && items[i].src < buf + size;
+              ctx->uploader.upload(items[i].dst, items[i].src, items[i].bytes, ctx->dev.device, cs,
+                                   from_file ? zkey_fd : -1, from_file ? (uint64_t)(items[i].src - buf) : 0);
             }
           }
           ready[items[i].id].set_value();
@@ -1279,7 +1283,7 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
 int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns,
                            uint64_t wtns_size, char* proof_buffer, unsigned long* proof_size, char* public_buffer,
                            unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize,
-                           zkpoa_zkey** out_zk) {
+                           zkpoa_zkey** out_zk, int zkey_fd = -1) {
   *out_zk = nullptr;
   const char* ov = getenv("ZKPOA_OVERLAP");
   auto tl0 = std::chrono::steady_clock::now();
@@ -1289,7 +1293,7 @@ int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zke
     const uint8_t *rp = nullptr, *sp = nullptr;
     env_blinding(rb, sb, rp, sp);
     auto t0 = std::chrono::steady_clock::now();
-    zkpoa_zkey* zk = load_prove_staged(ctx, zkey, zkey_size, w, parts);
+    zkpoa_zkey* zk = load_prove_staged(ctx, zkey, zkey_size, w, parts, zkey_fd);
     if (zk) {
       *out_zk = zk;
       zkey_header_bytes(zk, header);
@@ -1425,14 +1429,14 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
         try {
           rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
                                       proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
-                                      &zk);
+                                      &zk, fd);
         } catch (const HipError&) {
           if (g_key_cache.empty()) throw;
           key_cache_clear();                          // probably out of HBM: retry with nothing else resident
           (void)hipGetLastError();
           rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
                                       proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
-                                      &zk);
+                                      &zk, fd);
         }
         proved = true;
       } catch (...) {
