@@ -8,6 +8,7 @@
 #include <time.h>
 #include <condition_variable>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -101,6 +102,7 @@ struct DeviceCtx {
   // A stream of its own for host -> HBM copies that run WHILE lanes compute (one-shot proves overlap the zkey upload
   // with the MSMs). First thing the background thread creates; copy_stream_wait() blocks until it exists.
   hipStream_t copy_stream = nullptr;
+  std::function<void(hipStream_t)> after_copy_stream;   // runs on the background thread once the copy stream exists
   std::mutex copy_mutex_;
   std::condition_variable copy_cv_;
   bool copy_done_ = false;
@@ -134,6 +136,12 @@ struct DeviceCtx {
         ZK_HIP(hipSetDevice(device));
         hipError_t ce = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
         if (ce != hipSuccess) copy_stream = nullptr;
+        if (copy_stream && after_copy_stream) {
+          try {
+            after_copy_stream(copy_stream);
+          } catch (...) {   // only a head start: the first upload does it again
+          }
+        }
         {
           std::lock_guard<std::mutex> lk(copy_mutex_);
           copy_done_ = true;

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -74,6 +75,12 @@ class FastUploader {
       if (e) std::rethrow_exception(e);
   }
 
+  // pin the staging buffers ahead of the first upload (a one-shot prover: on the context's background thread)
+  void prepare(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(ensure_mutex_);
+    ensure_locked(device, stream);
+  }
+
   void release() {
     for (auto& s : slots_) {
       for (int b = 0; b < 2; b++) {
@@ -96,7 +103,12 @@ class FastUploader {
   void* block_ = nullptr;
   bool ready_ = false;
 
+  std::mutex ensure_mutex_;
   void ensure(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(ensure_mutex_);
+    ensure_locked(device, stream);
+  }
+  void ensure_locked(int device, hipStream_t stream) {
     if (ready_) return;
     ZK_HIP(hipSetDevice(device));
     ZK_HIP(hipHostMalloc(&block_, (size_t)kThreads * 2 * kChunk, hipHostMallocDefault));   // one pinning call

@@ -718,9 +718,9 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   uint8_t* outH = out + 320;
   std::exception_ptr errs[4];
   float msm_ms[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  const char* wit = reinterpret_cast<const char*>(zk->d_witness);
-  // A, B1 and B2 run over the compacted queries (points at infinity dropped at key load) and gathered scalars; the
-  // pointers are taken inside the stages (a staged prove builds the compacted queries there)
+  // A, B1 and B2 run over the compacted queries (points at infinity dropped at key load) and gathered scalars. Every
+  // device pointer is read INSIDE its stage, after the stage's staging hook: a staged prove allocates and fills the
+  // buffers while the stages are already waiting (a pointer taken here could still be null).
   const bool split = zk->split_world > 1;
   if (split && !zk->h_ready)
     throw ProverError(PROVER_ERROR, "split chain: run zkpoa_split_stage1/2/3 for this witness before zkpoa_prove_partials");
@@ -728,7 +728,6 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     for (int l = 1; l < 5; l++) ZK_HIP(hipStreamWaitEvent(ctx->dev.lanes[l].stream, ctx->ev_witness, 0));
     ctx->ev_witness_set = false;
   }
-  const char* witC = wit + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
   auto guarded = [&](int slot, std::function<void()> fn) {
     return std::thread([&, slot, fn] {
       try {
@@ -759,6 +758,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     if (stg && stg->prep_A) stg->prep_A();
     const MsmTable* useA = (zk->tA && zk->qA.lo == 0 && zk->qA.cnt == zk->qA.res) ? zk->tA : nullptr;
     const char* pA = reinterpret_cast<const char*>(zk->qA.g1) + zk->qA.lo * 64;
+    if (!zk->d_witness || !zk->qA.g1 || !zk->qA.scalars) throw ProverError(PROVER_ERROR, "internal: A stage started before its inputs");
     gather(1, zk->qA);
     msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1], useA);
   });
@@ -779,6 +779,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
       if (useB) msm_table_info(zk->tB1, tb_info);
       table_c_b = useB && share_b ? (int)tb_info[1] : 0;
       pB1 = reinterpret_cast<const char*>(zk->qB.g1) + zk->qB.lo * 64;
+      if (!zk->d_witness || !zk->qB.g1 || !zk->qB.g2 || !zk->qB.scalars)
+        throw ProverError(PROVER_ERROR, "internal: B stage started before its inputs");
       gather(2, zk->qB);
       auto ts0 = std::chrono::steady_clock::now();
       if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
@@ -805,6 +807,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     if (stg && stg->prep_C) stg->prep_C();
     const MsmTable* useC = (zk->tC && zk->clo == zk->cbase && !split_c_partial(zk)) ? zk->tC : nullptr;
     const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
+    const char* witC = reinterpret_cast<const char*>(zk->d_witness) + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
+    if (!zk->d_witness || (zk->ccnt && !zk->dC)) throw ProverError(PROVER_ERROR, "internal: C stage started before its inputs");
     msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC);
   });
   if (serial) tC.join();
@@ -814,6 +818,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   try {
     if (stg) deferred_free_sink() = &stg->sinks[4];
     if (stg && stg->prep_chain) stg->prep_chain();
+    if (!zk->d_witness || !zk->d_flag || (!split && (!zk->d_abc || !zk->d_row_ptr)))
+      throw ProverError(PROVER_ERROR, "internal: chain stage started before its inputs");
     // witness values must be canonical (< r): one streaming pass on the chain's lane, flag read with the H MSM's results
     ZK_HIP(hipMemsetAsync(zk->d_flag, 0, 4, l0.stream));
     range_check<FrParams>(l0.stream, zk->d_witness, zk->nVars, zk->d_flag);
@@ -826,6 +832,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     const MsmTable* useH = (!split && zk->tH && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr;
     const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
                            : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
+    if ((split ? (zk->dHs == nullptr) : (zk->hcnt && zk->dH == nullptr)))
+      throw ProverError(PROVER_ERROR, "internal: H stage started before its inputs");
     if (split) {
       // the three stages left this rank's H scalars (odd-coset indices = rank mod G) in d_abc[0 .. n/G)
       msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0]);
@@ -1012,6 +1020,13 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
   std::atomic<bool> cancel{false};
   std::thread uploader;
   Staging stg;
+  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&, verbose](const char* what) {   // ZKPOA_VERBOSE: the timeline of an overlapped load + prove
+    if (verbose)
+      fprintf(stderr, "zkpoa: staged %7.1f ms  %s\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what);
+  };
   auto cleanup_temps = [&] {
     (void)hipDeviceSynchronize();
     for (auto& v : stg.sinks) {
@@ -1025,52 +1040,55 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
   };
   try {
     auto alloc = [](void** p, uint64_t bytes) { ZK_HIP(hipMalloc(p, bytes ? bytes : 1)); };
-    alloc(&k->d_witness, m * 32);
-    alloc(&d_recs, zk->nCoefs * 44);
-    alloc(&k->dH, n * 64);
-    alloc(&k->dB1, m * 64);
-    alloc(&k->dB2, m * 128);
-    alloc(&k->dA, m * 64);
-    alloc(&k->dC, nC * 64);
     alloc(reinterpret_cast<void**>(&d_cflag), 64);
     ZK_HIP(hipMemset(d_cflag, 0, 64));
-    ctx->dev.wait_lanes();
-    struct Item { int id; void* dst; const uint8_t* src; uint64_t bytes; };
+    alloc(&k->d_witness, m * 32);
+    alloc(&d_recs, zk->nCoefs * 44);
+    // each buffer is allocated by the uploader right before its section moves (hipMalloc of GBs is milliseconds each)
+    struct Item { int id; void** dst; const uint8_t* src; uint64_t bytes; };
     const Item items[S_COUNT] = {
-        {S_WIT, k->d_witness, w.values, m * 32}, {S_COEF, d_recs, zs.s4.p + 4, zk->nCoefs * 44},
-        {S_H, k->dH, zs.s9.p, n * 64},           {S_B1, k->dB1, zs.s6.p, m * 64},
-        {S_B2, k->dB2, zs.s7.p, m * 128},        {S_A, k->dA, zs.s5.p, m * 64},
-        {S_C, k->dC, zs.s8.p, nC * 64}};
+        {S_WIT, &k->d_witness, w.values, m * 32}, {S_COEF, &d_recs, zs.s4.p + 4, zk->nCoefs * 44},
+        {S_H, &k->dH, zs.s9.p, n * 64},           {S_B1, &k->dB1, zs.s6.p, m * 64},
+        {S_B2, &k->dB2, zs.s7.p, m * 128},        {S_A, &k->dA, zs.s5.p, m * 64},
+        {S_C, &k->dC, zs.s8.p, nC * 64}};
     uploader = std::thread([&] {
       int i = 0;
       try {
         ZK_HIP(hipSetDevice(ctx->dev.device));
         for (; i < S_COUNT; i++) {
           if (cancel.load()) throw ProverError(PROVER_ERROR, "upload cancelled");
+          if (!*items[i].dst) ZK_HIP(hipMalloc(items[i].dst, items[i].bytes ? items[i].bytes : 1));
           if (items[i].bytes) {
             if (items[i].bytes < (4u << 20)) {   // small: one asynchronous copy on the copy stream (no null-stream copy here)
-              ZK_HIP(hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, cs));
+              ZK_HIP(hipMemcpyAsync(*items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, cs));
               ZK_HIP(hipStreamSynchronize(cs));
             } else {
               const bool from_file = zkey_fd >= 0 && items[i].src >= buf && items[i].src < buf + size;
-              ctx->uploader.upload(items[i].dst, items[i].src, items[i].bytes, ctx->dev.device, cs,
+              ctx->uploader.upload(*items[i].dst, items[i].src, items[i].bytes, ctx->dev.device, cs,
                                    from_file ? zkey_fd : -1, from_file ? (uint64_t)(items[i].src - buf) : 0);
             }
           }
           ready[items[i].id].set_value();
+          static const char* kNames[S_COUNT] = {"witness resident", "section 4 resident", "section 9 (H) resident",
+                                                "section 6 (B1) resident", "section 7 (B2) resident",
+                                                "section 5 (A) resident", "section 8 (C) resident"};
+          mark(kNames[items[i].id]);
         }
       } catch (...) {
         for (; i < S_COUNT; i++) ready[items[i].id].set_exception(std::current_exception());
       }
     });
+    ctx->dev.wait_lanes();   // the other lanes come up in the background while the first sections are already moving
     Lane* L = ctx->dev.lanes;
     stg.prep_chain = [&, k] {
       have[S_WIT].get();
       have[S_COEF].get();
       build_csr(ctx, k, d_recs, false, L[0].stream);
       ntt_prepare(ctx, L[0].stream, k->power);
+      mark("CSR + NTT tables built, H-scalar chain starts");
     };
     stg.prep_H = [&, k] {
+      mark("H-scalar chain enqueued");
       have[S_H].get();
       range_check<FqParams>(L[0].stream, k->dH, n * 2, d_cflag);
     };
@@ -1079,6 +1097,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       have[S_A].get();
       range_check<FqParams>(L[1].stream, k->dA, m * 2, d_cflag);
       query_compact(ctx, k, k->qA, k->dA, nullptr, m, L[1].stream);
+      mark("A query compacted, A MSM starts");
     };
     stg.prep_B = [&, k] {
       have[S_WIT].get();
@@ -1087,13 +1106,16 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       range_check<FqParams>(L[2].stream, k->dB1, m * 2, d_cflag);
       range_check<FqParams>(L[2].stream, k->dB2, m * 4, d_cflag);
       query_compact(ctx, k, k->qB, k->dB1, k->dB2, m, L[2].stream);
+      mark("B query compacted, B MSMs start");
     };
     stg.prep_C = [&, k] {
       have[S_WIT].get();
       have[S_C].get();
       range_check<FqParams>(L[4].stream, k->dC, nC * 2, d_cflag);
     };
+    mark("lanes up");
     prove_partials(ctx, k, parts, &stg);
+    mark("all five MSMs done");
     uploader.join();
     uint32_t bad = 0;
     ZK_HIP(hipDeviceSynchronize());
@@ -1105,6 +1127,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
     stg.sinks[4].push_back(k->dB2);
     k->dA = k->dB1 = k->dB2 = nullptr;
     cleanup_temps();
+    mark("temporaries freed");
   } catch (...) {
     cancel.store(true);
     if (uploader.joinable()) uploader.join();

@@ -22,6 +22,8 @@ extern "C" int zkpoa_context_create(int device, zkpoa_context** out, char* error
   *out = nullptr;
   zkpoa_context* c = new zkpoa_context();
   try {
+    // the uploader's pinned staging buffers (24 MiB, ~15 ms to pin) come up with the copy stream, off the main thread
+    c->dev.after_copy_stream = [c, device](hipStream_t st) { c->uploader.prepare(device, st); };
     c->dev.init(device);
     for (int i = 0; i < DeviceCtx::kLanes; i++) {
       ZK_HIP(hipEventCreate(&c->ev_a[i]));
