@@ -730,3 +730,41 @@ def test_out_of_range_field_elements_are_rejected(ctx, zk):
         bad[ps + 32:ps + 64] = bn.Q.to_bytes(32, "little")
         with pytest.raises(zk.ZkpoaError, match="coordinate is not a field element"):
             ctx.load_zkey(bytes(bad))
+
+
+def test_witness_generation_of_one_batch_overlaps_proving_of_another(zk, tmp_path):
+    """witness generation stays on the CPU (circom C++, 18 s - 2 min per proof in the reference's
+    logs, longer than the proving it feeds). The reference already runs its batches as parallel jobs
+    (scripts/full_workflow.sh:552: `parallel prove_layers_one_two`), each job = witness generator, then prover
+    (scripts/g16_prove.sh:228-252). With the resident prover (ZKPOA_SERVER) the GPU part of one job is a short
+    critical section, so batch i + 1's witness generation runs while batch i proves, with the scripts unchanged.
+    Here: three such jobs at once, the witness generator replaced by a 1-second stand-in; all three finish in about
+    one generator time, not three, and every proof has the golden bytes."""
+    import stat
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "ready.wtns").write_bytes(g["witness.wtns"])
+    gen = tmp_path / "witness_gen"
+    gen.write_text('#!/bin/bash\nsleep 1\ncp "%s" "$2"\n' % (tmp_path / "ready.wtns"))
+    gen.chmod(gen.stat().st_mode | stat.S_IXUSR)
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_SERVER=str(tmp_path / "p.sock"),
+               ZKPOA_SERVER_IDLE_S="60")
+    try:
+        # warm the server (its start-up and key upload are not what is measured)
+        subprocess.run([str(gen), "in.json", str(tmp_path / "w0.wtns")], check=True)
+        rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "w0.wtns", "p0.json", "u0.json"], env=env, cwd=tmp_path,
+                            capture_output=True, text=True, timeout=120)
+        assert rc.returncode == 0, rc.stderr
+        job = ('"%s" in.json "$1.wtns" && "%s" circuit_final.zkey "$1.wtns" "$1.proof.json" "$1.public.json"'
+               % (gen, zk.PROVER_BIN))
+        t0 = time.time()
+        procs = [subprocess.Popen(["bash", "-c", job, "job", "batch_%d" % i], env=env, cwd=tmp_path) for i in range(3)]
+        for pr in procs:
+            assert pr.wait(timeout=120) == 0
+        wall = time.time() - t0
+        for i in range(3):
+            assert (tmp_path / ("batch_%d.proof.json" % i)).read_text() == g["proof_rapidsnark.json"]
+        assert wall < 2.0, "three 1 s witness generators + proofs took %.2f s: the jobs did not overlap" % wall
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
