@@ -12,6 +12,7 @@
  *   orc_msm_g1/g2   = G1/G2.multiExpAffine (here: textbook Pippenger, unsigned c-bit windows,
  *                     threaded by window like rapidsnark's ParallelMultiexp)
  *   orc_prove       = groth16Prove (five MSMs + randomised assembly)
+ *   orc_poseidon2 / orc_merkle_levels = the anonymity-set Poseidon Merkle tree (scripts/merkle_tree.rs)
  *   orc_quotient_check = an NTT-free polynomial-identity test of a complete H-scalar vector (full-size pi_c checks)
  * Pinning: this file is checked against oracle/py (big-int Python), which is itself pinned by the
  * reference's committed proof/vkey fixtures through the pairing verifier; the (zkey, wtns) -> proof
@@ -564,6 +565,124 @@ int orc_prove(const void* zkey, uint64_t zkey_size, const void* wtns, uint64_t w
   g1_to_aff(&oa, &pa); g2_to_aff(&ob, &pb); g1_to_aff(&oc, &pc);
   memcpy(proof_points, &oa, 64); memcpy(proof_points + 64, &ob, 128); memcpy(proof_points + 192, &oc, 64);
   memcpy(public_le, w + 32, (size_t)npub * 32);
+  return 0;
+}
+
+/* ---- Poseidon (circomlib parameters, t = 3) and the anonymity-set Merkle tree ------------------------------------
+ * Restates what the reference's Rust binary computes (scripts/merkle_tree.rs:138-178 node hash, :206-269 leaves,
+ * :411 tree) through light-poseidon 0.2.0 `new_circom(2)` (Cargo.toml:11; not vendored): x^5 S-box, 8 full + 57
+ * partial rounds, parameters from the Poseidon reference generator -- an 80-bit Grain LFSR seeded with
+ * (field = 1, sbox = 0, n = 254, t, R_F, R_P, thirty 1-bits), 160 warm-up steps, self-shrinking output; constants by
+ * rejection sampling, MDS = Cauchy matrix 1 / (x_i + y_j). Pinned by tests/test_poseidon_oracle.py on circomlib's test
+ * vector and on the reference's committed Merkle root. */
+typedef struct { uint8_t st[80]; } grain;
+static int grain_step(grain* g) {
+  int nb = g->st[62] ^ g->st[51] ^ g->st[38] ^ g->st[23] ^ g->st[13] ^ g->st[0];
+  memmove(g->st, g->st + 1, 79); g->st[79] = (uint8_t)nb;
+  return nb;
+}
+static int grain_bit(grain* g) {
+  int nb = grain_step(g);
+  while (nb == 0) { grain_step(g); nb = grain_step(g); }
+  return grain_step(g);
+}
+static void grain_init(grain* g, unsigned t, unsigned rf, unsigned rp) {
+  unsigned pos = 0;
+  unsigned vals[6] = {1, 0, 254, t, rf, rp}, widths[6] = {2, 4, 12, 12, 10, 10};
+  for (int f = 0; f < 6; f++) for (int b = (int)widths[f] - 1; b >= 0; b--) g->st[pos++] = (vals[f] >> b) & 1;
+  while (pos < 80) g->st[pos++] = 1;
+  for (int i = 0; i < 160; i++) grain_step(g);
+}
+static void grain_254(grain* g, uint64_t out[4]) {   /* 254 bits, most significant first */
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (int i = 253; i >= 0; i--) if (grain_bit(g)) out[i >> 6] |= 1ull << (i & 63);
+}
+#define POS_T 3
+#define POS_RF 8
+#define POS_RP 57
+static fe POS_C[(POS_RF + POS_RP) * POS_T], POS_M[POS_T][POS_T];   /* Montgomery form */
+static int pos_ready = 0;
+static pthread_mutex_t pos_lock = PTHREAD_MUTEX_INITIALIZER;
+static void pos_init(void) {
+  pthread_mutex_lock(&pos_lock);
+  if (!pos_ready) {
+    grain g; grain_init(&g, POS_T, POS_RF, POS_RP);
+    for (int i = 0; i < (POS_RF + POS_RP) * POS_T;) {
+      fe v; grain_254(&g, v.v);
+      if (geq(v.v, RP)) continue;
+      fe_to_mont(&FR, &POS_C[i++], &v);
+    }
+    for (;;) {
+      fe xy[2 * POS_T]; int ok = 1;
+      for (int i = 0; i < 2 * POS_T; i++) { grain_254(&g, xy[i].v); if (geq(xy[i].v, RP)) sub_p(xy[i].v, RP); }
+      for (int i = 0; i < 2 * POS_T && ok; i++) for (int j = 0; j < i; j++) if (fe_eq(&xy[i], &xy[j])) ok = 0;
+      for (int i = 0; i < POS_T && ok; i++) for (int j = 0; j < POS_T; j++) {
+        fe s, a, b; fe_to_mont(&FR, &a, &xy[i]); fe_to_mont(&FR, &b, &xy[POS_T + j]); fe_add(&FR, &s, &a, &b);
+        if (fe_is_zero(&s)) { ok = 0; break; }
+        fe_inv(&FR, &POS_M[i][j], &s);
+      }
+      if (ok) break;
+    }
+    pos_ready = 1;
+  }
+  pthread_mutex_unlock(&pos_lock);
+}
+static void pos_pow5(fe* x) { fe x2, x4; fe_sqr(&FR, &x2, x); fe_sqr(&FR, &x4, &x2); fe_mul(&FR, x, &x4, x); }
+/* left, right, out: standard form */
+static void pos_hash2(fe* out, const fe* left, const fe* right) {
+  fe st[POS_T], nx[POS_T];
+  memset(&st[0], 0, sizeof(fe)); fe_to_mont(&FR, &st[1], left); fe_to_mont(&FR, &st[2], right);
+  for (int r = 0; r < POS_RF + POS_RP; r++) {
+    for (int i = 0; i < POS_T; i++) fe_add(&FR, &st[i], &st[i], &POS_C[r * POS_T + i]);
+    if (r < POS_RF / 2 || r >= POS_RF / 2 + POS_RP) for (int i = 0; i < POS_T; i++) pos_pow5(&st[i]);
+    else pos_pow5(&st[0]);
+    for (int i = 0; i < POS_T; i++) {
+      memset(&nx[i], 0, sizeof(fe));
+      for (int j = 0; j < POS_T; j++) { fe t; fe_mul(&FR, &t, &POS_M[i][j], &st[j]); fe_add(&FR, &nx[i], &nx[i], &t); }
+    }
+    memcpy(st, nx, sizeof(st));
+  }
+  fe_from_mont(&FR, out, &st[0]);
+}
+typedef struct { const fe* l; const fe* r; fe* o; uint64_t lo, hi, stride; } pos_job;
+static void* pos_worker(void* arg) {
+  pos_job* j = (pos_job*)arg;
+  for (uint64_t i = j->lo; i < j->hi; i++) pos_hash2(&j->o[i], &j->l[i * j->stride], &j->r[i * j->stride]);
+  return 0;
+}
+static void pos_many(const fe* l, const fe* r, uint64_t stride, fe* o, uint64_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if ((uint64_t)nthreads > n) nthreads = n ? (int)n : 1;
+  pos_job* jobs = (pos_job*)calloc((size_t)nthreads, sizeof(pos_job));
+  pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  for (int t = 0; t < nthreads; t++) {
+    jobs[t] = (pos_job){l, r, o, n * (uint64_t)t / (uint64_t)nthreads, n * (uint64_t)(t + 1) / (uint64_t)nthreads, stride};
+    if (t) pthread_create(&th[t], 0, pos_worker, &jobs[t]);
+  }
+  pos_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);
+  free(jobs); free(th);
+}
+/* n independent hashes: left, right, out = n x 32 B little-endian standard form */
+int orc_poseidon2(const void* left, const void* right, uint64_t n, void* out, int nthreads) {
+  pos_init();
+  pos_many((const fe*)left, (const fe*)right, 1, (fe*)out, n, nthreads);
+  return 0;
+}
+/* Merkle tree as merkle_tree.rs builds it: leaves[i] = H(address[i], balance[i]) for i < n, zero (unhashed) leaves up to
+ * 2^log_leaves, node = H(left, right). levels_out: (2^(log_leaves+1) - 1) x 32 B, leaves first, root last. */
+int orc_merkle_levels(const void* addresses, const void* balances, uint64_t n, unsigned log_leaves, void* levels_out,
+                      int nthreads) {
+  pos_init();
+  uint64_t N = 1ull << log_leaves;
+  if (n > N) return 1;
+  fe* lv = (fe*)levels_out;
+  memset(lv, 0, (size_t)N * 32);
+  pos_many((const fe*)addresses, (const fe*)balances, 1, lv, n, nthreads);
+  for (uint64_t w = N; w > 1; w >>= 1) {
+    pos_many(lv, lv + 1, 2, lv + w, w / 2, nthreads);
+    lv += w;
+  }
   return 0;
 }
 

@@ -24,6 +24,8 @@ def lib():
         L.orc_ntt.argtypes = [vp, ctypes.c_uint, ci]
         L.orc_h_scalars.argtypes = [vp, u64, vp, u64, ctypes.c_uint, vp]
         L.orc_quotient_check.argtypes = [vp, u64, vp, u64, ctypes.c_uint, vp, ctypes.c_char_p, ci]
+        L.orc_poseidon2.argtypes = [vp, vp, u64, vp, ci]
+        L.orc_merkle_levels.argtypes = [vp, vp, u64, ctypes.c_uint, vp, ci]
         L.orc_prove.argtypes = [vp, u64, vp, u64, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ci]
         L.orc_field_op.argtypes = [ci, ci, vp, vp, vp, u64]
         L.orc_group_add.argtypes = [ci, vp, vp, vp, u64]
@@ -109,6 +111,24 @@ def quotient_check(coeffs_section, witness, n_vars, k, h_scalars, z, nthreads=1)
     if rc not in (0, 1):
         raise ValueError("orc_quotient_check rc=%d" % rc)
     return rc == 0
+
+
+def poseidon2(left, right, nthreads=1):
+    """n independent circomlib Poseidon(2) hashes; left, right: n x 32 B LE standard form -> n x 32 B."""
+    n = len(left) // 32
+    out = ctypes.create_string_buffer(max(1, 32 * n))
+    lib().orc_poseidon2(bytes(left), bytes(right), n, out, nthreads)
+    return out.raw[:32 * n]
+
+
+def merkle_levels(addresses, balances, log_leaves, nthreads=1):
+    """All levels of the anonymity-set tree (leaves first, root last) as one byte string of (2^(k+1) - 1) x 32 B."""
+    n = len(addresses) // 32
+    out = ctypes.create_string_buffer(32 * ((2 << log_leaves) - 1))
+    rc = lib().orc_merkle_levels(bytes(addresses), bytes(balances), n, log_leaves, out, nthreads)
+    if rc:
+        raise ValueError("orc_merkle_levels rc=%d" % rc)
+    return out.raw
 
 
 def prove(zkey, wtns, r=0, s=0, nthreads=1, n_public=None):

@@ -1,0 +1,54 @@
+"""Oracle for the Poseidon Merkle tree of the anonymity set (scripts/merkle_tree.rs), pinned on the
+reference's own fixture: the committed anonymity set of tests/1_sigs_1_batches_5_height must hash to the Merkle root the
+reference logged (logs/merkle_tree.log:13) and proved against (layer_two/batch_0/public.json, second public signal)."""
+import csv
+import json
+import os
+import random
+
+import pytest
+
+from conftest import GOLDEN, le
+from oracle import c_oracle as co
+from oracle.py import poseidon as P
+
+REF_ROOT = 4980353021834912512710796692386145127886467347162150588171360986794629731619
+
+
+def anon_set():
+    rows = list(csv.reader(open(os.path.join(GOLDEN, "ref", "merkle", "anonymity_set_10.csv"))))[1:]
+    return [int(a[2:], 16) for a, _ in rows], [int(b) for _, b in rows]
+
+
+def test_parameters_match_circomlib():
+    C, M = P.params(3)
+    assert len(C) == 195 and C[0] == 0x0ee9a592ba9a9518d05986d656f40c2114c4993c11bb29938d21d47304cd8e6e
+    # circomlib test vector (test/poseidoncircuit.js): poseidon([1, 2])
+    assert P.poseidon([1, 2]) == 7853200120776062878684798364095072458815029376092732009249414926327459813530
+
+
+def test_reference_merkle_root_python_oracle():
+    addr, bal = anon_set()
+    levels = P.merkle_levels(addr, bal)
+    assert len(levels[0]) == 16 and levels[-1][0] == REF_ROOT
+    # the root is also what the reference's layer-two proof exposes as its second public signal
+    pub = json.load(open(os.path.join(GOLDEN, "ref", "1_sigs_1_batches_5_height__layer_two__batch_0", "public.json")))
+    assert int(pub[1]) == REF_ROOT
+    elems, idx = P.merkle_path(levels, 3)
+    node = levels[0][3]
+    for e, bit in zip(elems, idx):
+        node = P.poseidon([e, node] if bit else [node, e])
+    assert node == REF_ROOT
+
+
+def test_c_oracle_equals_python_oracle():
+    rng = random.Random(7)
+    xs = [0, 1, P.R - 1, 2 ** 160 - 1] + [rng.randrange(P.R) for _ in range(12)]
+    ys = [0, 2, P.R - 1, 5] + [rng.randrange(P.R) for _ in range(12)]
+    got = co.poseidon2(b"".join(le(x) for x in xs), b"".join(le(y) for y in ys), 3)
+    assert [int.from_bytes(got[32 * i:32 * i + 32], "little") for i in range(len(xs))] == [P.poseidon([x, y]) for x, y in zip(xs, ys)]
+    addr, bal = anon_set()
+    lv = co.merkle_levels(b"".join(le(a) for a in addr), b"".join(le(b) for b in bal), 4, 4)
+    flat = [v for level in P.merkle_levels(addr, bal) for v in level]
+    assert [int.from_bytes(lv[32 * i:32 * i + 32], "little") for i in range(31)] == flat
+    assert int.from_bytes(lv[-32:], "little") == REF_ROOT
