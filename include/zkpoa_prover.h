@@ -242,11 +242,37 @@ int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned long vkey_s
                                 unsigned long error_msg_maxsize);
 int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size);
 
+/* ---- the anonymity-set Merkle tree; GPU ------------------------------------------------------
+ * Stands in for the reference's Rust binary `merkle-tree` (scripts/merkle_tree.rs, run at
+ * scripts/full_workflow.sh:371-380): circomlib Poseidon(2) over Fr (light-poseidon `new_circom(2)`), leaf =
+ * H(address, balance), zero-valued leaves up to the next power of two, node = H(left, right).
+ * All field elements: 32 B little-endian standard form (the Rust code's big-endian byte arrays reversed).
+ * zkpoa_poseidon2: n independent hashes out[i] = H(left[i], right[i]).
+ * zkpoa_merkle_build: the whole tree for n (address, balance) pairs, kept in HBM; info: out = {n, path length
+ * (= rs_merkle depth() - 1), nodes}; root; stored leaves (hashes; zero for padding) for locating owned addresses
+ * (merkle_tree.rs:329-346); path: the sibling hashes of a leaf from the leaves up + the index bit per level, i.e. one
+ * entry of merkle_proofs.json's path_elements / path_indices (merkle_tree.rs:354-376).
+ * zkpoa_poseidon_params (host only, no GPU): the hash parameters as this library generates them (Grain LFSR), standard
+ * form: 195 round constants, then the 3 x 3 MDS matrix row-major. */
+typedef struct zkpoa_merkle zkpoa_merkle;
+int zkpoa_poseidon_params(uint8_t out[204 * 32]);
+int zkpoa_poseidon2(zkpoa_context* ctx, const void* left, const void* right, uint64_t n, void* out);
+int zkpoa_poseidon2_device(zkpoa_context* ctx, const void* d_left, const void* d_right, uint64_t n, void* d_out);
+int zkpoa_merkle_build(zkpoa_context* ctx, const void* addresses, const void* balances, uint64_t n, zkpoa_merkle** tree);
+int zkpoa_merkle_build_device(zkpoa_context* ctx, const void* d_addresses, const void* d_balances, uint64_t n,
+                              zkpoa_merkle** tree);
+void zkpoa_merkle_free(zkpoa_context* ctx, zkpoa_merkle* tree);
+int zkpoa_merkle_info(const zkpoa_merkle* tree, uint64_t out[3]);
+int zkpoa_merkle_root(zkpoa_context* ctx, const zkpoa_merkle* tree, uint8_t root_le[32]);
+int zkpoa_merkle_leaves(zkpoa_context* ctx, const zkpoa_merkle* tree, uint64_t first, uint64_t count, void* out);
+int zkpoa_merkle_path(zkpoa_context* ctx, const zkpoa_merkle* tree, uint64_t leaf_index, uint8_t* path_le,
+                      uint8_t* path_indices);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Timings (ms, HIP events on the stream that ran the kernels) of the last call on this context.
  * id: 0 = whole device part of last MSM, 1 = its bucket-accumulation kernel (dominant kernel),
  *     2 = last NTT, 3 = last prove: ABC+NTT chain, 4 = last prove: all MSMs, 5 = last prove: total,
- *     6 = last prove: self-check (host pairing check; 0 when it did not run).
+ *     6 = last prove: self-check (host pairing check; 0 when it did not run), 7 = last Merkle tree build.
  * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto); key "msm_max_points" sets the
  * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values);
  * key "prove_serial" = 1 runs the stages of a prove one after the other (solo device times for the roofline). */

@@ -21,7 +21,7 @@ def zk():
     """The product package (zk-proof-of-assets_amd/, loaded as module zkpoa_amd)."""
     import __graft_entry__ as entry
     mod = entry.load_package()
-    if not (os.path.exists(mod.LIB_PATH) and os.path.exists(mod.PROVER_BIN) and os.path.exists(mod.VERIFY_BIN)):
+    if not all(os.path.exists(p) for p in (mod.LIB_PATH, mod.PROVER_BIN, mod.VERIFY_BIN, mod.MERKLE_BIN)):
         entry.build()           # fresh checkout: compile the HIP library + CLIs (hipcc cross-compiles without a GPU)
     return mod
 

@@ -52,3 +52,26 @@ def test_c_oracle_equals_python_oracle():
     flat = [v for level in P.merkle_levels(addr, bal) for v in level]
     assert [int.from_bytes(lv[32 * i:32 * i + 32], "little") for i in range(31)] == flat
     assert int.from_bytes(lv[-32:], "little") == REF_ROOT
+
+
+def test_library_parameters_equal_the_oracle(zk):
+    """The product generates the Poseidon parameters itself (csrc/poseidon.hip, host side, Grain LFSR): all 195 round
+    constants and the MDS matrix must equal the oracle's, i.e. circomlib's. Host only: no GPU needed."""
+    C, M = zk.poseidon_params()
+    oc, om = P.params(3)
+    assert C == oc and M == om
+
+
+def test_merkle_cli_fails_loudly_without_gpu(zk, tmp_path):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked tests")
+    (tmp_path / "poa.json").write_text('{"accountAttestations": []}')
+    rc = subprocess.run([zk.MERKLE_BIN, "--anon-set", os.path.join(GOLDEN, "ref", "merkle", "anonymity_set_10.csv"),
+                         "--poa-input-data", str(tmp_path / "poa.json"), "--output-dir", str(tmp_path)],
+                        capture_output=True, text=True, timeout=120)
+    assert rc.returncode != 0 and "no HIP device" in rc.stderr
+    assert not (tmp_path / "merkle_root.json").exists()
+    rc = subprocess.run([zk.MERKLE_BIN], capture_output=True, text=True)
+    assert rc.returncode == 2 and "--anon-set" in rc.stderr

@@ -16,6 +16,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkpoa_prover.so")
 PROVER_BIN = os.path.join(_HERE, "prover")
+MERKLE_BIN = os.path.join(_HERE, "merkle-tree")
 
 PROVER_OK = 0
 PROVER_ERROR = 1
@@ -42,6 +43,8 @@ EXPORTS = [
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
     "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
     "zkpoa_context_stream", "zkpoa_context_synchronize",
+    "zkpoa_poseidon_params", "zkpoa_poseidon2", "zkpoa_poseidon2_device", "zkpoa_merkle_build", "zkpoa_merkle_build_device", "zkpoa_merkle_free",
+    "zkpoa_merkle_info", "zkpoa_merkle_root", "zkpoa_merkle_leaves", "zkpoa_merkle_path",
     "zkpoa_msm_table_build", "zkpoa_msm_table_free", "zkpoa_msm_table_info", "zkpoa_msm_table_run_lane",
 ]
 
@@ -76,6 +79,16 @@ def lib():
         L.zkpoa_context_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.zkpoa_context_stream.restype = ctypes.c_void_p
         L.zkpoa_context_synchronize.argtypes = [ctypes.c_void_p]
+        for name in ("zkpoa_poseidon2", "zkpoa_poseidon2_device"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        for name in ("zkpoa_merkle_build", "zkpoa_merkle_build_device"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, c_void_pp]
+        L.zkpoa_merkle_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_merkle_free.restype = None
+        L.zkpoa_merkle_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.zkpoa_merkle_root.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.zkpoa_merkle_leaves.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.zkpoa_merkle_path.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         L.zkpoa_last_error.argtypes = [ctypes.c_void_p]
         L.zkpoa_last_error.restype = ctypes.c_char_p
         L.zkpoa_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -261,6 +274,23 @@ class Context:
     def last_ms_lane(self, lane, ident):
         return float(lib().zkpoa_last_ms_lane(self._h, lane, ident))
 
+    # ---- the anonymity-set Merkle tree (scripts/merkle_tree.rs) ---------------------------------------------------
+    def poseidon2(self, left, right):
+        """n independent circomlib Poseidon(2) hashes; left, right: n x 32 B LE standard form -> n x 32 B."""
+        n = len(left) // 32
+        pl, kl = _buf(left)
+        pr, kr = _buf(right)
+        out = ctypes.create_string_buffer(max(1, 32 * n))
+        self._check(lib().zkpoa_poseidon2(self._h, pl, pr, n, out), "zkpoa_poseidon2")
+        return out.raw[:32 * n]
+
+    def poseidon2_device(self, d_left, d_right, n, d_out):
+        self._check(lib().zkpoa_poseidon2_device(self._h, d_left, d_right, n, d_out), "zkpoa_poseidon2_device")
+
+    def merkle_build(self, addresses, balances, device=False, n=None):
+        """Tree over (address, balance) pairs: host buffers (n x 32 B LE each) or, with device=True, device pointers."""
+        return MerkleTree(self, addresses, balances, device, n)
+
     def msm_table(self, group, d_bases, n, window_bits=0):
         """Fixed-base table over n device-resident bases (group 1 = G1, 2 = G2) -> MsmTable."""
         return MsmTable(self, group, d_bases, n, window_bits)
@@ -408,6 +438,58 @@ class Context:
         return proof.raw, pub.raw[:32 * npub]
 
 
+class MerkleTree:
+    """The anonymity-set Poseidon Merkle tree resident in HBM (zkpoa_merkle_build)."""
+
+    def __init__(self, ctx, addresses, balances, device=False, n=None):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        if device:
+            ctx._check(lib().zkpoa_merkle_build_device(ctx._h, addresses, balances, n, ctypes.byref(self._h)),
+                       "zkpoa_merkle_build_device")
+        else:
+            n = len(addresses) // 32 if n is None else n
+            pa, ka = _buf(addresses)
+            pb, kb = _buf(balances)
+            ctx._check(lib().zkpoa_merkle_build(ctx._h, pa, pb, n, ctypes.byref(self._h)), "zkpoa_merkle_build")
+
+    def info(self):
+        """(n, path length, nodes)"""
+        out = (ctypes.c_uint64 * 3)()
+        lib().zkpoa_merkle_info(self._h, out)
+        return tuple(int(v) for v in out)
+
+    def root(self):
+        out = ctypes.create_string_buffer(32)
+        self._ctx._check(lib().zkpoa_merkle_root(self._ctx._h, self._h, out), "zkpoa_merkle_root")
+        return int.from_bytes(out.raw, "little")
+
+    def leaves(self, first=0, count=None):
+        count = (1 << self.info()[1]) - first if count is None else count
+        out = ctypes.create_string_buffer(max(1, 32 * count))
+        self._ctx._check(lib().zkpoa_merkle_leaves(self._ctx._h, self._h, first, count, out), "zkpoa_merkle_leaves")
+        return out.raw[:32 * count]
+
+    def path(self, index):
+        """(sibling hashes from the leaves up as ints, index bits)"""
+        k = self.info()[1]
+        elems = ctypes.create_string_buffer(max(1, 32 * k))
+        bits = ctypes.create_string_buffer(max(1, k))
+        self._ctx._check(lib().zkpoa_merkle_path(self._ctx._h, self._h, index, elems, bits), "zkpoa_merkle_path")
+        return ([int.from_bytes(elems.raw[32 * i:32 * i + 32], "little") for i in range(k)], list(bits.raw[:k]))
+
+    def close(self):
+        if self._h and self._ctx._h:
+            lib().zkpoa_merkle_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MsmTable:
     """Fixed-base table 2^(c*j) * P_i of a resident base array (zkpoa_msm_table_build)."""
 
@@ -530,6 +612,16 @@ def groth16_verify(vkey_json, public_json, proof_json):
     if rc == 0x10:
         return False
     raise ZkpoaError("zkpoa_groth16_verify: " + err.value.decode())
+
+
+def poseidon_params():
+    """(round constants, MDS rows) the library generates (host only), as Python ints."""
+    buf = ctypes.create_string_buffer(204 * 32)
+    lib().zkpoa_poseidon_params.argtypes = [ctypes.c_void_p]
+    if lib().zkpoa_poseidon_params(buf) != PROVER_OK:
+        raise ZkpoaError("zkpoa_poseidon_params failed")
+    vals = [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(204)]
+    return vals[:195], [vals[195 + 3 * i:198 + 3 * i] for i in range(3)]
 
 
 def groth16_verify_points(vkey_points, proof_points, public_le):

@@ -48,6 +48,7 @@ extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
   }
   ntt_release(ctx);
+  poseidon_release(ctx);
   ctx->uploader.release();
   ctx->dev.destroy();
   delete ctx;

@@ -13,8 +13,11 @@ struct NttEngine;
 struct MsmTable;
 }
 
+struct zkpoa_poseidon_state;   // poseidon.hip: device copy of the Poseidon parameters
+
 struct zkpoa_context {
   zkpoa::DeviceCtx dev;
+  zkpoa_poseidon_state* poseidon = nullptr;
   zkpoa::NttEngine* ntt = nullptr;
   zkpoa::FastUploader uploader;   // pinned, multi-threaded host -> HBM path for zkey sections / witnesses
   std::string last_error;
@@ -101,6 +104,7 @@ void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool 
 void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h,
                    uint32_t rank_stride);
 void ntt_release(zkpoa_context* ctx);
+void poseidon_release(zkpoa_context* ctx);
 }  // namespace zkpoa
 
 #define ZK_API_BEGIN(ctx)  \
