@@ -6,7 +6,7 @@ points / scalars, inputs resident in HBM. One "step" = one complete MSM over the
 slice (weak scaling: with N ranks the job is one N*2^20-point MSM whose per-rank partial points are
 all-gathered over RCCL and summed on every rank -- SURVEY.md 8e).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm_g1_2p20|msm_g1_2pXX|prove_2pXX] [--no-also]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm_g1_2p20|msm_g1_2pXX|prove_2pXX|merkle_<leaves>] [--no-also]
 
 Prints ONE JSON line on rank 0. BASELINE.json's metric is "Groth16 proofs/sec + G1-MSM pts/s at 2^20 / 2^26", so
 with N = 1 and the default workload the same line carries, under "also", the other shapes of that metric measured
@@ -431,6 +431,95 @@ def prove_leg(env, k, steps, warmup, precompute=True):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+MODMUL_PEAK_G = 130.0       # 254-bit Montgomery products/s, register-only loop on one MI355X (tools/microbench2.hip)
+POSEIDON_MODMULS = 8 * 18 + 57 * 12 + 3     # per hash: full rounds 3 S-boxes + 9 MDS products, partial 1 + 9, form changes
+
+
+def merkle_leg(env, n_leaves, steps, warmup, cpu_baseline=True):
+    """The anonymity-set Poseidon Merkle tree (scripts/merkle_tree.rs): n (address, balance) pairs
+    resident in HBM -> all levels of the tree. One step = one complete tree."""
+    import numpy as np
+    import torch
+    ctx = env.ctx
+    nr = np.random.default_rng(0x5EED0020)
+    a = np.zeros((n_leaves, 4), dtype=np.uint64)
+    b = np.zeros((n_leaves, 4), dtype=np.uint64)
+    a[:, 0] = nr.integers(0, 1 << 63, size=n_leaves, dtype=np.uint64)
+    a[:, 1] = nr.integers(0, 1 << 63, size=n_leaves, dtype=np.uint64)
+    a[:, 2] = nr.integers(0, 1 << 32, size=n_leaves, dtype=np.uint64)       # 160-bit addresses
+    b[:, 0] = nr.integers(0, 1 << 63, size=n_leaves, dtype=np.uint64)
+    b[:, 1] = nr.integers(0, 1 << 26, size=n_leaves, dtype=np.uint64)       # 90-bit balances (wei)
+    da = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(env.dev)
+    db = torch.from_numpy(b.view(np.uint8).reshape(-1)).to(env.dev)
+    k = max(0, (n_leaves - 1).bit_length())
+    hashes = n_leaves + (1 << k) - 1
+
+    def build():
+        t = ctx.merkle_build(da.data_ptr(), db.data_ptr(), device=True, n=n_leaves)
+        ms = ctx.last_ms(7)
+        return t, ms
+
+    for _ in range(warmup):
+        build()[0].close()
+    env.sync()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    tree = None
+    for _ in range(steps):
+        if tree is not None:
+            tree.close()
+        tree, ms = build()
+        dev_ms += ms
+    env.sync()
+    elapsed = time.perf_counter() - t0
+    # correctness of what was timed: the root folds from a sampled leaf through its path with the CPU oracle's hash,
+    # and a 2^12-leaf prefix tree equals the oracle's tree
+    from oracle import c_oracle as co
+    root = tree.root()
+    ok = True
+    for idx in (0, n_leaves - 1, n_leaves // 3):
+        elems, bits = tree.path(idx)
+        node = co.poseidon2(a[idx].tobytes(), b[idx].tobytes(), 1)
+        for e, bit in zip(elems, bits):
+            eb = int(e).to_bytes(32, "little")
+            node = co.poseidon2(eb, node, 1) if bit else co.poseidon2(node, eb, 1)
+        ok = ok and int.from_bytes(node, "little") == root
+    tree.close()
+    env.agree(ok, "Merkle root does not fold from sampled leaves with the oracle's Poseidon")
+    sec = elapsed / steps
+    kernel_s = dev_ms / steps * 1e-3
+    line = {
+        "metric": "Poseidon Merkle tree build", "value": n_leaves / sec, "unit": "leaves/s",
+        "n_gpus": env.world, "steps": steps, "warmup": warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": "Poseidon(2) Merkle tree of %d (address, balance) leaves padded to 2^%d (scripts/merkle_tree.rs; "
+                               "its header quotes 2.5 hours for a 10 M set on the CPU), inputs resident in HBM" % (n_leaves, k),
+                   "hashes_per_tree": hashes,
+                   "checked": "root folded from 3 sampled leaves through their paths with the CPU oracle's Poseidon"},
+        "roofline": {"bound": "hbm", "kernel": "poseidon2_kernel (all levels of one tree)",
+                     "achieved": 96.0 * hashes / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": 96.0 * hashes / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_s * 1e3,
+                     "valu": {"unit": "G modmul/s", "achieved": POSEIDON_MODMULS * hashes / kernel_s / 1e9,
+                              "peak": MODMUL_PEAK_G, "frac": POSEIDON_MODMULS * hashes / kernel_s / 1e9 / MODMUL_PEAK_G,
+                              "hashes_per_s": hashes / kernel_s, "modmul_per_hash": POSEIDON_MODMULS},
+                     "note": "algorithmic bytes = 64 B in + 32 B out per hash; the hash is %d Montgomery products: "
+                             "integer-VALU-bound" % POSEIDON_MODMULS},
+    }
+    if cpu_baseline:
+        cores = host_cores()
+        ns = 1 << 16
+        tc = time.perf_counter()
+        co.poseidon2(a[:ns].tobytes(), b[:ns].tobytes(), cores)
+        tcpu = time.perf_counter() - tc
+        line["cpu_baseline"] = {"value": ns / tcpu, "unit": "hashes/s", "cores": cores, "kind": "port",
+                                "sample": "2^16 leaf hashes of the same workload, C oracle (oracle/c) on every host core of "
+                                          "the job; the reference's Rust binary is single-threaded", "seconds": tcpu}
+    del da, db
+    torch.cuda.empty_cache()
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -489,6 +578,8 @@ def main():
         if args.workload.startswith("prove_2p"):
             line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
                              precompute=not args.no_precompute)
+        elif args.workload.startswith("merkle_"):
+            line = merkle_leg(env, int(float(args.workload[len("merkle_"):])), args.steps, args.warmup)
         elif args.workload.startswith("msm_g1_2p"):
             line = msm_leg(env, int(args.workload[len("msm_g1_2p"):]), args.steps, args.warmup, args.inflight,
                            fixed_base=args.fixed_base, cpu_baseline=(world == 1 and not args.no_cpu_baseline))
@@ -502,12 +593,13 @@ def main():
                     ("msm_g1_2p26", lambda: msm_leg(env, 26, 5, 2, 3)),
                     ("msm_g1_2p26_fixed_base", lambda: msm_leg(env, 26, 5, 2, 3, fixed_base=True)),
                     ("prove_2p21", lambda: prove_leg(env, 21, 20, 3)),
-                    ("prove_2p26", lambda: prove_leg(env, 26, 3, 1))):
+                    ("prove_2p26", lambda: prove_leg(env, 26, 3, 1)),
+                    ("merkle_10M", lambda: merkle_leg(env, 10_000_000, 3, 1))):
                 t0 = time.perf_counter()
                 leg = fn()
                 entry = {"workload": name}
                 entry.update({kk: leg[kk] for kk in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config",
-                                                      "roofline")})
+                                                      "roofline", "cpu_baseline") if kk in leg})
                 entry["leg_seconds"] = time.perf_counter() - t0
                 also.append(entry)
             line["also"] = also

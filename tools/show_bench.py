@@ -4,7 +4,9 @@ l = json.loads([x for x in open(sys.argv[1]).read().strip().splitlines() if x.st
 def show(e, name):
     r = e["roofline"]
     print("%-26s %12.4g %-9s ms/step %8.3f steps %d" % (name, e["value"], e["unit"], e["ms_per_step"], e["steps"]), end=" ")
-    if "kernel_ms" in r:
+    if "modmul_per_hash" in r.get("valu", {}):
+        print("| tree %.2f ms, %.1f M hashes/s, valu frac %.3f" % (r["kernel_ms"], r["valu"]["hashes_per_s"] / 1e6, r["valu"]["frac"]))
+    elif "kernel_ms" in r:
         print("| accum solo %.3f ms (overlapped %.3f) hbm frac %.4f valu %.3f c=%d W=%d msm solo %.2f" % (
             r["kernel_ms"], r["kernel_ms_overlapped"], r["frac"], r["valu"]["frac"], r["valu"]["window_bits"],
             r["valu"]["windows"], r["msm_device_ms_solo"]))
