@@ -163,7 +163,7 @@ def msm_leg(env, logn, steps, warmup, inflight, fixed_base=False, cpu_baseline=F
     # host thread: the sort / bucket-reduction / read-back / host-Horner phases of one MSM are small or
     # latency-bound and overlap with the accumulation kernel of the next (the prover does the same with
     # its five MSMs). Collectives stay on the main thread, in step order.
-    inflight = max(1, min(inflight, 6))
+    inflight = max(1, min(inflight, 12))
     pool = ThreadPoolExecutor(inflight)
 
     def msm_on(lane):
@@ -532,7 +532,7 @@ def main():
     ap.add_argument("--no-precompute", action="store_true", help="prove workloads: no fixed-base tables")
     ap.add_argument("--replicated-chain", action="store_true",
                     help="prove workloads, N > 1: run the whole H-scalar chain on every rank instead of splitting it")
-    ap.add_argument("--inflight", type=int, default=6, help="MSMs kept in flight on separate HIP streams (1..6)")
+    ap.add_argument("--inflight", type=int, default=6, help="MSMs kept in flight on separate HIP streams (1..12)")
     args = ap.parse_args()
 
     import torch

@@ -91,8 +91,10 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
 struct DeviceCtx {
   int device = 0;
   int num_cu = 256;
-  static constexpr int kLanes = 6;
+  static constexpr int kLanes = 12;      // lanes a caller may address (zkpoa_msm_g1_device_lane ...)
+  static constexpr int kEagerLanes = 6;  // created with the context (the prover uses 0-4); the rest on first use
   Lane lanes[kLanes];
+  std::mutex lazy_mutex_;
   bool ok = false;
   // last-run kernel timing (HIP events on the lane's stream), for bench.py's roofline object
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -147,7 +149,7 @@ struct DeviceCtx {
           copy_done_ = true;
         }
         copy_cv_.notify_all();
-        for (int i = 1; i < kLanes; i++) lanes[i].init(i == 3 ? 1 : 0);
+        for (int i = 1; i < kEagerLanes; i++) lanes[i].init(i == 3 ? 1 : 0);
       } catch (...) {
         bg_err_ = std::current_exception();
         {
@@ -159,7 +161,7 @@ struct DeviceCtx {
     });
     if (verbose)
       fprintf(stderr, "zkpoa: HIP runtime up in %.1f ms, first lane in %.1f ms (the other %d in the background)\n",
-              t1 - t0, now_ms() - t1, kLanes - 1);
+              t1 - t0, now_ms() - t1, kEagerLanes - 1);
     ok = true;
   }
   // the copy stream (nullptr when it could not be created: callers then copy on lane 0's stream)
@@ -167,6 +169,15 @@ struct DeviceCtx {
     std::unique_lock<std::mutex> lk(copy_mutex_);
     copy_cv_.wait(lk, [this] { return copy_done_; });
     return copy_stream;
+  }
+  // lanes kEagerLanes.. come up the first time somebody asks for them (a stream costs ~12 ms to create)
+  void ensure_lane(int i) {
+    if (i < kEagerLanes) return;
+    std::lock_guard<std::mutex> lk(lazy_mutex_);
+    if (!lanes[i].stream) {
+      ZK_HIP(hipSetDevice(device));
+      lanes[i].init(0);
+    }
   }
   // every lane other than 0 may only be used after this (cheap once the background thread has been joined)
   void wait_lanes() {

@@ -12,6 +12,7 @@ template <class F, class HF>
 void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d_scalars, uint64_t n, uint8_t* out,
              float* ms2, const MsmTable* table = nullptr) {
   if (lane_id) ctx->dev.wait_lanes();
+  ctx->dev.ensure_lane(lane_id);
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char> wsums((size_t)64 * MsmSizes<F>::kXyzz * 2);
   const uint64_t max_pts = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
