@@ -768,3 +768,69 @@ def test_witness_generation_of_one_batch_overlaps_proving_of_another(zk, tmp_pat
         assert wall < 2.0, "three 1 s witness generators + proofs took %.2f s: the jobs did not overlap" % wall
     finally:
         subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
+# ---- the one-shot entry points overlap the key upload with the compute (load_prove_staged) -----------------------
+def _one_shot(zk, zkey, wt, env_overlap, monkeypatch, r_, s_):
+    import ctypes
+    monkeypatch.setenv("ZKPOA_R", str(r_))
+    monkeypatch.setenv("ZKPOA_S", str(s_))
+    if env_overlap is None:
+        monkeypatch.delenv("ZKPOA_OVERLAP", raising=False)
+    else:
+        monkeypatch.setenv("ZKPOA_OVERLAP", env_overlap)
+    L = zk.lib()
+    psz, usz = ctypes.c_ulong(1 << 12), ctypes.c_ulong(1 << 16)
+    proof, public, err = ctypes.create_string_buffer(psz.value), ctypes.create_string_buffer(usz.value), ctypes.create_string_buffer(1024)
+    rc = L.groth16_prover(zkey, len(zkey), wt, len(wt), proof, ctypes.byref(psz), public, ctypes.byref(usz), err, 1024)
+    return rc, proof.value.decode(), public.value.decode(), err.value.decode()
+
+
+@pytest.mark.parametrize("nVars,nPublic,nCons", [
+    (30, 0, 20), (40, 3, 60), (9, 1, 1),
+    (5, 1, 2),          # the smallest circuits the generator makes: 3 private wires
+    (6, 2, 3),
+    (700, 2, 900),      # a few sort tiles, every lane busy
+])
+def test_one_shot_staged_equals_sequential_and_oracle(zk, monkeypatch, nVars, nPublic, nCons):
+    """groth16_prover (the buffer form of what the CLI does) with the upload overlapped (default) and with
+    ZKPOA_OVERLAP=0: identical JSON, equal to the oracle's proof, self-check on, over the edge shapes of the domain."""
+    rng = random.Random(nVars * 77 + nCons)
+    zkey, vk, w = _setup_small(rng, nVars, nPublic, nCons)
+    wt = g16.write_wtns(w)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    monkeypatch.delenv("ZKPOA_SELFCHECK", raising=False)
+    rc1, p1, u1, e1 = _one_shot(zk, zkey, wt, None, monkeypatch, r_, s_)
+    rc0, p0, u0, e0 = _one_shot(zk, zkey, wt, "0", monkeypatch, r_, s_)
+    assert rc1 == 0 and rc0 == 0, (e1, e0)
+    assert (p1, u1) == (p0, u0)
+    proof, opub = g16.prove(zkey, wt, r_, s_)
+    assert p1 == g16.proof_json_rapidsnark(proof) and u1 == g16.public_json_rapidsnark(opub)
+    assert zk.groth16_verify(json.dumps(vk), u1, p1)
+    # errors of the staged path: wrong witness length (rapidsnark's code 3), corrupted coordinate, bad witness value
+    rc, _, _, err = _one_shot(zk, zkey, g16.write_wtns(w + [1]), None, monkeypatch, r_, s_)
+    assert rc == 3 and "Invalid witness length" in err
+    secs = g16.read_binfile(zkey, "zkey", 2)
+    p9, _ = secs[9][0]
+    bad = bytearray(zkey)
+    bad[p9:p9 + 32] = bn.Q.to_bytes(32, "little")
+    rc, _, _, err = _one_shot(zk, bytes(bad), wt, None, monkeypatch, r_, s_)
+    assert rc == 1 and "coordinate is not a field element" in err
+    wraw = bytearray(wt)                                   # (write_wtns reduces mod r: patch the bytes)
+    wraw[-32:] = R.to_bytes(32, "little")
+    rc, _, _, err = _one_shot(zk, zkey, bytes(wraw), None, monkeypatch, r_, s_)
+    assert rc == 1 and "witness value is not a field element" in err
+    rc, p2, u2, e2 = _one_shot(zk, zkey, wt, None, monkeypatch, r_, s_)      # and the context is still good
+    assert rc == 0 and (p2, u2) == (p1, u1), e2
+
+
+def test_one_shot_staged_mid_size(zk, mid_circuit, monkeypatch):
+    zkey, _, wt, _ = mid_circuit
+    rng = random.Random(12)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    rc1, p1, u1, e1 = _one_shot(zk, zkey, wt, None, monkeypatch, r_, s_)
+    rc0, p0, u0, e0 = _one_shot(zk, zkey, wt, "0", monkeypatch, r_, s_)
+    assert rc1 == 0 and rc0 == 0, (e1, e0)
+    assert (p1, u1) == (p0, u0)
+    proof, opub = co.prove(zkey, wt, r_, s_, 8)
+    assert p1 == zk.proof_to_json(proof)
