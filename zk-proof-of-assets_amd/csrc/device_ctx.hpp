@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
+#include <atomic>
 #include <condition_variable>
+#include <string.h>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -129,10 +131,12 @@ struct DeviceCtx {
     num_cu = prop.multiProcessorCount;
     double t1 = now_ms();
     // lane 0 carries the prover's critical path (H-scalar chain -> H MSM): highest stream priority
-    // and lane 3 (the G2 MSM, the longest of the witness MSMs) the middle one.
     // A stream with its pinned buffer and events costs ~12 ms to create: lane 0 now, the others on a background
     // thread (they are first needed by the MSMs of a prove, after the key has been uploaded) -> wait_lanes().
-    lanes[0].init(2);
+    {
+      const char* pe0 = getenv("ZKPOA_LANE_PRIO");
+      lanes[0].init(pe0 && !strcmp(pe0, "none") ? 0 : 2);
+    }
     bg_ = std::thread([this] {
       try {
         ZK_HIP(hipSetDevice(device));
@@ -149,7 +153,15 @@ struct DeviceCtx {
           copy_done_ = true;
         }
         copy_cv_.notify_all();
-        for (int i = 1; i < kEagerLanes; i++) lanes[i].init(i == 3 ? 1 : 0);
+        // Stream priorities, two lanes per level (high, high, middle, middle, low, low). Measured on one box
+        // (tools/ab_streams.sh): every lane at the same priority costs 8-10 % of the six-in-flight MSM rate and of a
+        // 2^21 proof (the lanes then move in lock step and their accumulation kernels collide); which lanes get which
+        // level matters little (within 3 %); ZKPOA_LANE_PRIO = flat | none | ladder2 selects the other patterns tried.
+        const char* pe = getenv("ZKPOA_LANE_PRIO");
+        const bool flat = pe && !strcmp(pe, "flat"), none = pe && !strcmp(pe, "none"), ladder2 = pe && !strcmp(pe, "ladder2");
+        static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1};
+        for (int i = 1; i < kEagerLanes; i++)
+          lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
       } catch (...) {
         bg_err_ = std::current_exception();
         {
