@@ -10,18 +10,20 @@
 //
 // Pipeline (all kernels on one stream; one 16-byte read-back to size the launches):
 //   1 digits   : scalar -> sign-normalised (s > r/2 -> r-s, negate base) signed c-bit digits.
-//   2 sort     : two-level MSD counting sort of (point, window) entries by bucket on LDS histograms
-//                (msm_sort.hip.h): per-task LDS histogram, one global atomic per (task, bin) to reserve
-//                ranges, scan, LDS-ranked scatter. The hot key of real witnesses (|digit| = 1, i.e.
-//                scalars 0/1/-1) is aggregated per wavefront with a 64-bit ballot.
+//   2 sort     : MSD counting sort of the (point, window) entries by bucket in passes of <= 8 key bits, every
+//                pass staged through LDS (msm_sort.hip.h): per-task LDS histogram, one global atomic per
+//                (task, bin) to reserve ranges, scan, LDS-regrouped coalesced scatter. The hot key of real
+//                witnesses (|digit| = 1, i.e. scalars 0/1/-1) is aggregated per wavefront with a 64-bit ballot.
 //   3 scan     : exclusive scans (bucket offsets, piece offsets).
 //   4 accumulate (level 0): buckets are cut into pieces of <= K0 entries, pieces are ordered by length
 //                (longest first) and one thread sums one piece with XYZZ mixed additions (gather of
 //                64/128-B affine bases). Work per thread is bounded whatever the scalar distribution;
 //                buckets with more than one piece are finished by further levels over the partial sums.
-//   5 reduce   : sum_b b*B[b] per window: threads take 8-bucket segments (running sums), weight
-//                them by the segment index, then an LDS tree sums segments per window.
-//   6 host     : W window sums -> Horner over 2^c on the host (O(W*c) group ops).
+//   5 reduce   : sum_b (b+1)*B[b] per bucket set from the row and column sums of the rows x S bucket matrix
+//                (2 independent additions per bucket), small double-and-add weights, LDS tree.
+//   6 host     : per bucket set 2^logS * U + V, then Horner over 2^c across the windows (O(W*c) group ops).
+// Fixed-base form (MsmTable, below): with 2^(c*j) * P_i precomputed for every window, all windows share one
+// bucket set and the same kernels run over n * W entries.
 #pragma once
 #include "bn254_ec.hip.h"
 #include "device_ctx.hpp"
