@@ -53,6 +53,16 @@ struct MsmPlan {
 };
 
 inline uint32_t msm_windows(uint32_t c) { return (254 + c - 1) / c; }
+// Density hint of the calling thread (the prover's witness stages set it): density[c] = expected non-zero digits per
+// scalar at window width c, 4 <= c <= 25, measured on this proof's witness (msm_density_kernel). Real witnesses are
+// mostly bits and short limbs, so a witness MSM has a fraction of the n * W entries of a uniform one -- and a window
+// sized for n * W entries then pays for millions of near-empty buckets (2^26 shape: the A query took 34 ms for 10 ms
+// of additions). nullptr = uniform scalars (every digit non-zero).
+constexpr int kDensityLo = 4, kDensityHi = 25;
+inline const double*& msm_density_hint() {
+  static thread_local const double* hint = nullptr;
+  return hint;
+}
 // experiments (zkpoa_set_option "msm_k0"): force the level-0 piece length; 0 = the rule below
 inline int& msm_forced_k0() {
   static int k0 = 0;
@@ -68,11 +78,16 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   p.merged = merged;
   int best_c = 4;
   double best = 1e300;
+  const double* density = merged ? nullptr : msm_density_hint();
   for (int c = 4; c <= (merged ? 25 : 22); c++) {
     double W = (double)msm_windows((uint32_t)c);
     double sets = merged ? 1.0 : W;
     double passes = (double)((c - 1 + 7) / 8);
-    double cost = W * (double)n * (1.0 + 0.03 * passes) + 3.0 * sets * (double)(1u << (c - 1));
+    // entries that exist; the dense n x W digit matrix is still written once and read twice (0.04 of an addition
+    // per slot), and every bucket costs a slot in the piece list besides its two additions in the reduction
+    double entries = density ? density[c] * (double)n : W * (double)n;
+    double cost = entries * (1.0 + 0.03 * passes) + (density ? 0.04 * W * (double)n : 0.0) +
+                  (density ? 5.0 : 3.0) * sets * (double)(1u << (c - 1));
     if (cost < best) {
       best = cost;
       best_c = c;
@@ -92,7 +107,8 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   // K0 dependent mixed additions have run, and a G2 addition is ~15 us for a lone wave (256 of them: 4 ms), so
   // a sort whose result also feeds a G2 accumulation (the prover's B query) uses a quarter of that; buckets
   // longer than K0 continue in the partial-sum levels.
-  double avg = (double)p.ne / (double)p.Nb;
+  const double dens_entries = density ? density[p.c] * (double)p.n : (double)p.n * p.W;
+  double avg = (merged ? (double)p.ne : dens_entries / p.W) / (double)p.Nb;
   uint32_t k0 = 32;
   while (k0 < 2 * avg && k0 < 256) k0 <<= 1;
   if (for_g2 && k0 > 32) k0 = k0 >= 128 ? k0 / 4 : 32;
@@ -100,7 +116,7 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   // accumulation kernel's 3 waves per SIMD; 2 for G2): with fewer, longer pieces the grid is one partial wave of
   // work and the CUs idle behind its longest pieces (2^20 points: 128-long pieces ran at 0.84 of the ALU ceiling,
   // 32-long ones at 0.95-1.0; the extra partial sums cost ~3 % more additions).
-  const double fill = (double)p.n * p.W / (2.5 * 256.0 * (for_g2 ? 8.0 : 12.0) * 64.0);
+  const double fill = dens_entries / (2.5 * 256.0 * (for_g2 ? 8.0 : 12.0) * 64.0);
   while (k0 > 32 && (double)k0 > fill) k0 >>= 1;
   if (msm_forced_k0() >= 8 && msm_forced_k0() <= (int)kMaxPieceLenPlan) k0 = (uint32_t)msm_forced_k0();
   p.K0 = k0;
@@ -135,6 +151,37 @@ ZK_DEV void load_scalar(const void* scalars, uint32_t i, uint32_t (&s)[8]) {
   uint4 a = p[0], b = p[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
   s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+
+// non-zero c-bit digits of the sign-normalised scalars, summed over the array, for every c in [kDensityLo, kDensityHi]:
+// ~ceil(bitlength / c) each. out[c - kDensityLo] (u64, zeroed by the caller).
+static __global__ __launch_bounds__(256) void msm_density_kernel(const void* __restrict__ scalars, uint64_t n,
+                                                                 unsigned long long* __restrict__ out) {
+  __shared__ unsigned int acc[kDensityHi - kDensityLo + 1];
+  if (threadIdx.x <= (unsigned)(kDensityHi - kDensityLo)) acc[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  uint32_t L = 0;
+  if (i < n) {
+    uint32_t s[8];
+    const uint4* p = reinterpret_cast<const uint4*>(scalars) + 2 * i;
+    uint4 a = p[0], b = p[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    (void)scalar_normalize(s);
+#pragma unroll
+    for (int k = 7; k >= 0; k--)
+      if (L == 0 && s[k]) L = 32u * k + (32u - __builtin_clz(s[k]));
+  }
+  for (int c = kDensityLo; c <= kDensityHi; c++) {
+    uint32_t d = (L + c - 1) / c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63u) == 0 && d) atomicAdd(&acc[c - kDensityLo], d);
+  }
+  __syncthreads();
+  if (threadIdx.x <= (unsigned)(kDensityHi - kDensityLo) && acc[threadIdx.x])
+    atomicAdd(&out[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
 // ---- 2: scan (u32, exclusive, n+1 outputs) ----------------------------------------------------

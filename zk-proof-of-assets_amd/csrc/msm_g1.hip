@@ -25,6 +25,18 @@ void msm_table_release(MsmTable* t) {
 }
 const void* msm_table_data(const MsmTable* t) { return t ? t->d : nullptr; }
 void msm_set_forced_k0(int k0) { msm_forced_k0() = k0; }
+void msm_set_density_hint(const double* density) { msm_density_hint() = density; }
+void msm_density(hipStream_t st, const void* d_scalars, uint64_t n, double out[32], void* d_scratch) {
+  for (int c = 0; c < 32; c++) out[c] = (double)msm_windows(c < 4 ? 4u : (uint32_t)c);   // uniform default
+  if (n == 0) return;
+  unsigned long long h[kDensityHi - kDensityLo + 1];
+  ZK_HIP(hipMemsetAsync(d_scratch, 0, 32 * 8, st));
+  hipLaunchKernelGGL(msm_density_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n,
+                     (unsigned long long*)d_scratch);
+  ZK_HIP(hipMemcpyAsync(h, d_scratch, sizeof(h), hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  for (int c = kDensityLo; c <= kDensityHi; c++) out[c] = (double)h[c - kDensityLo] / (double)n;
+}
 void msm_table_info(const MsmTable* t, uint64_t out[4]) {
   out[0] = t->n;
   out[1] = t->c;

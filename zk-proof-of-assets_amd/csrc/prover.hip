@@ -239,7 +239,7 @@ void build_csr(zkpoa_context* ctx, zkpoa_zkey* zk, const void* d_recs, bool loca
   // work area: the chain transforms A_T, B_T, C_T in place (a split shard: its n / G rows of each)
   if (!zk->d_abc) ZK_HIP(hipMalloc(&zk->d_abc, (size_t)3 * (n >> lp) * 32));
   if (!zk->d_witness) ZK_HIP(hipMalloc(&zk->d_witness, (size_t)m * 32));
-  if (!zk->d_flag) ZK_HIP(hipMalloc(reinterpret_cast<void**>(&zk->d_flag), 64));
+  if (!zk->d_flag) ZK_HIP(hipMalloc(reinterpret_cast<void**>(&zk->d_flag), 1024));   // + scratch of msm_density at +256
   DevBuf d_cnt((size_t)rows * 4), d_rank((size_t)(zk->nCoefs ? zk->nCoefs : 1) * 4),
       d_bs(((size_t)rows / kScanTile + 2) * 4), d_misc(64);
   ZK_HIP(hipMalloc(&zk->d_row_ptr, ((size_t)rows + 1) * 4));
@@ -744,6 +744,21 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   // (lane 2) and both accumulations read it; A and C sort on their own lanes.
   std::promise<const MsmSorted*> sorted_promise;
   std::shared_future<const MsmSorted*> sorted_ready = sorted_promise.get_future().share();
+  // digit density of this proof's witness (non-zero digits per scalar for every window width), measured once by the
+  // first witness stage that gets there, on its own lane; the classic-form witness MSMs size their windows with it
+  std::once_flag density_once;
+  double density[32];
+  bool density_ok = false;
+  auto with_density = [&](int lane_id) -> const double* {
+    const char* nd = getenv("ZKPOA_NO_DENSITY");
+    if ((nd && *nd && strcmp(nd, "0") != 0) || !zk->d_flag || !zk->d_witness) return nullptr;
+    std::call_once(density_once, [&] {
+      msm_density(ctx->dev.lanes[lane_id].stream, zk->d_witness, zk->nVars, density,
+                  reinterpret_cast<char*>(zk->d_flag) + 256);
+      density_ok = true;
+    });
+    return density_ok ? density : nullptr;
+  };
   auto gather = [&](int lane_id, const zkpoa_zkey::CompactQuery& q) {
     if (q.cnt)
       hipLaunchKernelGGL(gather32_kernel, dim3((uint32_t)((q.cnt * 2 + 255) / 256)), dim3(256), 0,
@@ -759,6 +774,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     const MsmTable* useA = (zk->tA && zk->qA.lo == 0 && zk->qA.cnt == zk->qA.res) ? zk->tA : nullptr;
     const char* pA = reinterpret_cast<const char*>(zk->qA.g1) + zk->qA.lo * 64;
     if (!zk->d_witness || !zk->qA.g1 || !zk->qA.scalars) throw ProverError(PROVER_ERROR, "internal: A stage started before its inputs");
+    msm_set_density_hint(with_density(1));
     gather(1, zk->qA);
     msm_run_g1(ctx, 1, pA, zk->qA.scalars, zk->qA.cnt, outA, msm_ms[1], useA);
   });
@@ -781,6 +797,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
       pB1 = reinterpret_cast<const char*>(zk->qB.g1) + zk->qB.lo * 64;
       if (!zk->d_witness || !zk->qB.g1 || !zk->qB.g2 || !zk->qB.scalars)
         throw ProverError(PROVER_ERROR, "internal: B stage started before its inputs");
+      msm_set_density_hint(with_density(2));
       gather(2, zk->qB);
       auto ts0 = std::chrono::steady_clock::now();
       if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
@@ -809,6 +826,7 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
     const char* witC = reinterpret_cast<const char*>(zk->d_witness) + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
     if (!zk->d_witness || (zk->ccnt && !zk->dC)) throw ProverError(PROVER_ERROR, "internal: C stage started before its inputs");
+    msm_set_density_hint(with_density(4));
     msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC);
   });
   if (serial) tC.join();
@@ -1044,6 +1062,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
     ZK_HIP(hipMemset(d_cflag, 0, 64));
     alloc(&k->d_witness, m * 32);
     alloc(&d_recs, zk->nCoefs * 44);
+    alloc(reinterpret_cast<void**>(&k->d_flag), 1024);
     // each buffer is allocated by the uploader right before its section moves (hipMalloc of GBs is milliseconds each)
     struct Item { int id; void** dst; const uint8_t* src; uint64_t bytes; };
     const Item items[S_COUNT] = {

@@ -77,6 +77,10 @@ void msm_table_release(MsmTable* t);
 const void* msm_table_data(const MsmTable* t);
 void msm_table_info(const MsmTable* t, uint64_t out[4]);   // n, c, W, bytes
 void msm_set_forced_k0(int k0);
+// non-zero digits per scalar for every window width (index c, 4..25) of n scalars on the device; synchronises st
+// (d_scratch: 256 B of device memory of the caller's -- no allocation here: a hipFree would wait for every lane)
+void msm_density(hipStream_t st, const void* d_scalars, uint64_t n, double out[32], void* d_scratch);
+void msm_set_density_hint(const double* density);   // for the calling thread; nullptr = uniform scalars
 void group_add_run_g1(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void group_add_run_g2(zkpoa_context* ctx, const void* a, const void* b, void* out, uint64_t n);
 void gen_bases_g1(zkpoa_context* ctx, const uint8_t a_le[32], const uint8_t b_le[32], uint64_t i0, uint64_t n, void* d_out);
