@@ -241,6 +241,12 @@ int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned long vkey_s
                                 const uint8_t* public_le, unsigned long n_public, char* error_msg,
                                 unsigned long error_msg_maxsize);
 int zkpoa_zkey_vkey(const zkpoa_zkey* zkey, uint8_t* buffer, unsigned long* size);
+/* `snarkjs zkey export verificationkey <zkey> <vkey.json>` (scripts/g16_setup.sh:287-293), host only: the text of
+ * <circuit>_vkey.json from the zkey image's sections 1-3, byte for byte what snarkjs writes (1-space indent,
+ * vk_alphabeta_12 included); pinned on the reference's committed *_vkey.json. Size protocol as groth16_prover.
+ * CLI: `zkpoa-verify --export-vkey <zkey> <vkey.json>`. */
+int zkpoa_zkey_export_vkey(const void* zkey_buffer, unsigned long zkey_size, char* buffer, unsigned long* size,
+                           char* error_msg, unsigned long error_msg_maxsize);
 
 /* ---- the anonymity-set Merkle tree; GPU ------------------------------------------------------
  * Stands in for the reference's Rust binary `merkle-tree` (scripts/merkle_tree.rs, run at

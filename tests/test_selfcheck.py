@@ -197,3 +197,40 @@ def test_cli_selfcheck_exit_code_and_no_partial_output(zk, tmp_path):
                         capture_output=True, text=True)
     assert rc.returncode != 0 and "self-check failed" in rc.stderr
     assert not (tmp_path / "proof.json").exists() and not (tmp_path / "public.json").exists()
+
+
+# ---- `snarkjs zkey export verificationkey` from zkey sections 1-3, pinned on the reference's *_vkey.json -------------
+def _zkey_with_vkey(vkey):
+    """A zkey image holding just what the export reads: section 1 (protocol), 2 (header), 3 (IC), built from a vkey."""
+    R_ = R
+    hdr = struct.pack("<I", 32) + Q.to_bytes(32, "little") + struct.pack("<I", 32) + R_.to_bytes(32, "little")
+    hdr += struct.pack("<III", 1000, int(vkey["nPublic"]), 1024)
+    dummy_g1 = _g1(vkey["vk_alpha_1"])
+    hdr += _g1(vkey["vk_alpha_1"]) + dummy_g1 + _g2(vkey["vk_beta_2"]) + _g2(vkey["vk_gamma_2"]) + dummy_g1 + _g2(vkey["vk_delta_2"])
+    ic = b"".join(_g1(p) for p in vkey["IC"])
+    return g16.write_binfile("zkey", 1, [(1, struct.pack("<I", 1)), (2, hdr), (3, ic)])
+
+
+@pytest.mark.parametrize("vkf", ["layer_one_vkey.json", "layer_two_vkey.json", "layer_three_vkey.json"])
+def test_export_vkey_reproduces_reference_files(zk, vkf, tmp_path):
+    """Byte for byte the reference's committed <circuit>_vkey.json (snarkjs output), vk_alphabeta_12 included."""
+    text = open(os.path.join(REF, vkf)).read()
+    z = _zkey_with_vkey(json.loads(text))
+    assert zk.export_vkey(z) == text
+    (tmp_path / "c.zkey").write_bytes(z)
+    rc = subprocess.run([zk.VERIFY_BIN, "--export-vkey", str(tmp_path / "c.zkey"), str(tmp_path / "vkey.json")],
+                        capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr
+    assert (tmp_path / "vkey.json").read_text() == text
+    with pytest.raises(zk.ZkpoaError):
+        zk.export_vkey(z[:40])
+
+
+@pytest.mark.parametrize("tag", ["n8", "n128"])
+def test_export_vkey_of_golden_zkeys(zk, tag):
+    g = golden_case(tag)
+    got = json.loads(zk.export_vkey(g["circuit.zkey"]))
+    want = json.loads(g["vkey.json"])
+    assert {k: v for k, v in got.items() if k != "vk_alphabeta_12"} == want
+    # and the exported key verifies the golden proof
+    assert zk.groth16_verify(json.dumps(got), g["public_rapidsnark.json"], g["proof_rapidsnark.json"])

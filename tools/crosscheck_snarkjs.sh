@@ -7,7 +7,8 @@
 # What it does, mirroring the reference's own prove -> verify sequence
 # (scripts/g16_prove.sh:246-252, scripts/g16_verify.sh:213-216, scripts/g16_setup.sh:287-293):
 #   1. `prover zkey wtns proof.json public.json`               (this repo's drop-in, self-check ON)
-#   2. `snarkjs zkey export verificationkey zkey vkey.json`    (the reference's own export)
+#   2. `snarkjs zkey export verificationkey zkey vkey.json`    (the reference's own export), byte-compared with
+#      `zkpoa-verify --export-vkey` on the same zkey
 #   3. `snarkjs groth16 verify vkey.json public.json proof.json`  -> must print "snarkJS: OK!"
 #   4. the native verifier on the same three files            -> must agree
 #   5. `snarkjs groth16 prove` on the same inputs; public.json must be byte-identical, and with
@@ -30,6 +31,10 @@ ZKPOA_SELFCHECK=all ZKPOA_VERBOSE=1 "$PROVER" "$ZKEY" "$WTNS" "$WORK/proof.json"
 
 echo "== 2. snarkjs zkey export verificationkey"
 $SNARKJS zkey export verificationkey "$ZKEY" "$WORK/vkey.json"
+
+echo "== 2b. our export of the same key must be byte-identical (zkey sections 2-3 decoded with the same conventions)"
+"$VERIFY" --export-vkey "$ZKEY" "$WORK/vkey_ours.json"
+cmp "$WORK/vkey.json" "$WORK/vkey_ours.json"
 
 echo "== 3. snarkjs groth16 verify (the reference's acceptance check, g16_verify.sh:213-216)"
 $SNARKJS groth16 verify "$WORK/vkey.json" "$WORK/public.json" "$WORK/proof.json" | tee "$WORK/verify.log"

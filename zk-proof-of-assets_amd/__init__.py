@@ -40,7 +40,7 @@ EXPORTS = [
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
     "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
-    "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey",
+    "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey", "zkpoa_zkey_export_vkey",
     "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
     "zkpoa_context_stream", "zkpoa_context_synchronize",
     "zkpoa_poseidon_params", "zkpoa_poseidon2", "zkpoa_poseidon2_device", "zkpoa_merkle_build", "zkpoa_merkle_build_device", "zkpoa_merkle_free",
@@ -612,6 +612,23 @@ def groth16_verify(vkey_json, public_json, proof_json):
     if rc == 0x10:
         return False
     raise ZkpoaError("zkpoa_groth16_verify: " + err.value.decode())
+
+
+def export_vkey(zkey_bytes):
+    """`snarkjs zkey export verificationkey`: the text of <circuit>_vkey.json from a zkey image (host only)."""
+    L = lib()
+    L.zkpoa_zkey_export_vkey.argtypes = [ctypes.c_void_p, ctypes.c_ulong, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_ulong), ctypes.c_void_p, ctypes.c_ulong]
+    p, k = _buf(zkey_bytes)
+    size = ctypes.c_ulong(0)
+    err = ctypes.create_string_buffer(512)
+    rc = L.zkpoa_zkey_export_vkey(p, len(zkey_bytes), None, ctypes.byref(size), err, 512)
+    if rc != PROVER_ERROR_SHORT_BUFFER:
+        raise ZkpoaError("zkpoa_zkey_export_vkey: " + err.value.decode())
+    buf = ctypes.create_string_buffer(size.value)
+    if L.zkpoa_zkey_export_vkey(p, len(zkey_bytes), buf, ctypes.byref(size), err, 512) != PROVER_OK:
+        raise ZkpoaError("zkpoa_zkey_export_vkey: " + err.value.decode())
+    return buf.value.decode()
 
 
 def poseidon_params():

@@ -219,6 +219,156 @@ extern "C" int zkpoa_groth16_verify(const char* vkey_json, const char* public_js
   }
 }
 
+// ---- `snarkjs zkey export verificationkey` (scripts/g16_setup.sh:287-293) from zkey sections 1-3 --------------------
+// The text snarkjs writes: JSON.stringify(vKey, null, 1) with the keys protocol, curve, nPublic, vk_alpha_1, vk_beta_2,
+// vk_gamma_2, vk_delta_2, vk_alphabeta_12, IC (format and values pinned by the reference's committed *_vkey.json).
+// vk_alphabeta_12 is wasmcurves' pairing value: e(alpha1, beta2) raised to 2x(6x^2 + 3x + 1), x = 4965661367192848881
+// (SURVEY.md 8c), laid out [w^k][v^j] = Fq2 [c0, c1] in the 2-3-2 tower, which is this file's Fq12 as it stands.
+namespace {
+struct JOut {   // JSON.stringify(., null, 1): one space per nesting level
+  std::string s;
+  void indent(int d) { s.append((size_t)d, ' '); }
+  void str(const std::string& v) { s += "\"" + v + "\""; }
+  void g1(const G1& p, int d) {
+    const bool inf = p.is_inf();
+    std::string c[3] = {inf ? "0" : p.x.to_dec(), inf ? "1" : p.y.to_dec(), inf ? "0" : "1"};
+    s += "[\n";
+    for (int i = 0; i < 3; i++) {
+      indent(d + 1);
+      str(c[i]);
+      s += i < 2 ? ",\n" : "\n";
+    }
+    indent(d);
+    s += "]";
+  }
+  void fq2(const HFq2& v, int d) {
+    s += "[\n";
+    indent(d + 1);
+    str(v.c0.to_dec());
+    s += ",\n";
+    indent(d + 1);
+    str(v.c1.to_dec());
+    s += "\n";
+    indent(d);
+    s += "]";
+  }
+  void g2(const G2& p, int d) {
+    const bool inf = p.is_inf();
+    HFq2 one = HFq2::one(), zero = HFq2::zero();
+    const HFq2 c[3] = {inf ? zero : p.x, inf ? one : p.y, inf ? zero : one};
+    s += "[\n";
+    for (int i = 0; i < 3; i++) {
+      indent(d + 1);
+      // the third coordinate is the plain pair ["1", "0"], not a Montgomery-decoded value
+      if (i == 2) {
+        s += "[\n";
+        indent(d + 2);
+        str(inf ? "0" : "1");
+        s += ",\n";
+        indent(d + 2);
+        str("0");
+        s += "\n";
+        indent(d + 1);
+        s += "]";
+      } else {
+        fq2(c[i], d + 1);
+      }
+      s += i < 2 ? ",\n" : "\n";
+    }
+    indent(d);
+    s += "]";
+  }
+};
+
+uint32_t le32(const uint8_t* p) {
+  uint32_t v;
+  memcpy(&v, p, 4);
+  return v;
+}
+
+std::string export_vkey_impl(const uint8_t* buf, uint64_t size) {
+  if (size < 12 || memcmp(buf, "zkey", 4) != 0) throw std::runtime_error("zkey file: invalid file format (bad magic)");
+  const uint32_t nsec = le32(buf + 8);
+  const uint8_t *s2 = nullptr, *s3 = nullptr;
+  uint64_t l2 = 0, l3 = 0, pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > size) throw std::runtime_error("zkey file: truncated section table");
+    uint32_t id = le32(buf + pos);
+    uint64_t len;
+    memcpy(&len, buf + pos + 4, 8);
+    pos += 12;
+    if (len > size - pos) throw std::runtime_error("zkey file: truncated section");
+    if (id == 2 && !s2) { s2 = buf + pos; l2 = len; }
+    if (id == 3 && !s3) { s3 = buf + pos; l3 = len; }
+    pos += len;
+  }
+  const uint64_t hdr = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128;
+  if (!s2 || l2 < hdr || !s3) throw std::runtime_error("zkey file: missing groth16 header (section 2) or IC (section 3)");
+  const uint32_t n_public = le32(s2 + 76);
+  if (l3 != ((uint64_t)n_public + 1) * 64) throw std::runtime_error("zkey file: section 3 (IC) has the wrong size");
+  const uint8_t* p = s2 + 84;
+  G1 alpha1 = h_affine_from_bytes<HFq>(p);
+  G2 beta2 = h_affine_from_bytes<HFq2>(p + 128), gamma2 = h_affine_from_bytes<HFq2>(p + 256);
+  G2 delta2 = h_affine_from_bytes<HFq2>(p + 448);
+  // e(alpha1, beta2)^(2x(6x^2+3x+1)): 190-bit exponent, little-endian limbs
+  static const uint64_t kFc[3] = {0x2e5d4e223ddedaf4ull, 0x1ea96b02d9d9e38dull, 0x3bec47df15e307c8ull};
+  Fq12 e = pairing::pairing(beta2, alpha1), ab = Fq12::one();
+  for (int i = 2; i >= 0; i--)
+    for (int b = 63; b >= 0; b--) {
+      ab = ab.sqr();
+      if ((kFc[i] >> b) & 1) ab = ab * e;
+    }
+  JOut o;
+  o.s = "{\n \"protocol\": \"groth16\",\n \"curve\": \"bn128\",\n \"nPublic\": " + std::to_string(n_public) + ",\n \"vk_alpha_1\": ";
+  o.g1(alpha1, 1);
+  o.s += ",\n \"vk_beta_2\": ";
+  o.g2(beta2, 1);
+  o.s += ",\n \"vk_gamma_2\": ";
+  o.g2(gamma2, 1);
+  o.s += ",\n \"vk_delta_2\": ";
+  o.g2(delta2, 1);
+  o.s += ",\n \"vk_alphabeta_12\": [\n";
+  const Fq6* half[2] = {&ab.c0, &ab.c1};
+  for (int k = 0; k < 2; k++) {
+    const HFq2 c[3] = {half[k]->c0, half[k]->c1, half[k]->c2};
+    o.s += "  [\n";
+    for (int j = 0; j < 3; j++) {
+      o.s += "   ";
+      o.fq2(c[j], 3);
+      o.s += j < 2 ? ",\n" : "\n";
+    }
+    o.s += k < 1 ? "  ],\n" : "  ]\n";
+  }
+  o.s += " ],\n \"IC\": [\n";
+  for (uint32_t i = 0; i <= n_public; i++) {
+    o.s += "  ";
+    o.g1(h_affine_from_bytes<HFq>(s3 + 64 * (uint64_t)i), 2);
+    o.s += i < n_public ? ",\n" : "\n";
+  }
+  o.s += " ]\n}";
+  return o.s;
+}
+}  // namespace
+
+extern "C" int zkpoa_zkey_export_vkey(const void* zkey_buffer, unsigned long zkey_size, char* buffer, unsigned long* size,
+                                      char* error_msg, unsigned long error_msg_maxsize) {
+  if (!size || !zkey_buffer) return PROVER_ERROR;
+  try {
+    std::string s = export_vkey_impl(reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size);
+    unsigned long needed = (unsigned long)s.size() + 1;
+    if (!buffer || *size < needed) {
+      *size = needed;
+      return PROVER_ERROR_SHORT_BUFFER;
+    }
+    memcpy(buffer, s.c_str(), needed);
+    *size = needed;
+    return PROVER_OK;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+}
+
 // Same check on wire-format points (what a zkey and the prover hold): no JSON, no decimal conversion.
 extern "C" int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned long vkey_size,
                                            const uint8_t proof_points[256], const uint8_t* public_le,
