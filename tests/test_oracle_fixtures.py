@@ -23,7 +23,7 @@ CASES_4SIG = [
     ("4_sigs_2_batches_12_height__layer_two__batch_1", "layer_two_vkey.json"),
     ("4_sigs_2_batches_12_height__layer_three", "layer_three_vkey.json"),
 ]
-ALL_DIRS = sorted(d for d in os.listdir(REF) if os.path.isdir(os.path.join(REF, d)) and d != "snarkjs_style")
+ALL_DIRS = sorted(d for d in os.listdir(REF) if os.path.isdir(os.path.join(REF, d)) and d not in ("snarkjs_style", "merkle"))
 
 
 def _load(d, name):
