@@ -10,10 +10,13 @@ for old in glob.glob(os.path.join(DST, RND + "_*")):
 
 def only(pattern):
     """exactly one match: gpurun merges into an existing gpurun_out/, so stale runs must be deleted first"""
-    fs = glob.glob(pattern)
-    if len(fs) != 1:
-        sys.exit("expected one file for %s, found %d: rm -rf gpurun_out/profiles_<round> and collect again" % (pattern, len(fs)))
-    return fs[0]
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    if not fs:
+        sys.exit("no file for %s: collect again" % pattern)
+    if len(fs) > 1:          # gpurun merges into an existing gpurun_out/: the newest run wins, the stale ones go
+        for old in fs[:-1]:
+            shutil.rmtree(os.path.dirname(old), ignore_errors=True) if os.path.dirname(old) != os.path.dirname(fs[-1]) else os.remove(old)
+    return fs[-1]
 
 
 def last_json_line(path):
