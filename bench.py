@@ -432,7 +432,8 @@ def prove_leg(env, k, steps, warmup, precompute=True):
 
 # ---------------------------------------------------------------------------------------------------------------
 MODMUL_PEAK_G = 130.0       # 254-bit Montgomery products/s, register-only loop on one MI355X (tools/microbench2.hip)
-POSEIDON_MODMULS = 8 * 18 + 57 * 12 + 3     # per hash: full rounds 3 S-boxes + 9 MDS products, partial 1 + 9, form changes
+POSEIDON_MODMULS = 8 * 18 + 4 + 57 * 8 + 3   # per hash as the kernel computes it: full rounds 3 S-boxes + 9 MDS products,
+                                            # one 2 x 2 product, sparse partial rounds 3 + 5, form changes (poseidon.hip)
 
 
 def merkle_leg(env, n_leaves, steps, warmup, cpu_baseline=True):
@@ -579,7 +580,9 @@ def main():
             line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
                              precompute=not args.no_precompute)
         elif args.workload.startswith("merkle_"):
-            line = merkle_leg(env, int(float(args.workload[len("merkle_"):])), args.steps, args.warmup)
+            spec = args.workload[len("merkle_"):]            # merkle_10000000, merkle_1e7, merkle_10M, merkle_64k
+            mult = {"k": 10**3, "K": 10**3, "M": 10**6}.get(spec[-1:], 1)
+            line = merkle_leg(env, int(float(spec[:-1] if mult > 1 else spec) * mult), args.steps, args.warmup)
         elif args.workload.startswith("msm_g1_2p"):
             line = msm_leg(env, int(args.workload[len("msm_g1_2p"):]), args.steps, args.warmup, args.inflight,
                            fixed_base=args.fixed_base, cpu_baseline=(world == 1 and not args.no_cpu_baseline))

@@ -8,16 +8,26 @@
 // partial rounds; its parameters come from the Poseidon reference generator (Grain LFSR), regenerated here on the
 // host (the crates are not vendored) and pinned by the reference's committed anonymity set / Merkle root.
 //
-// Device mapping: one hash per lane, the 3-element state in registers (24 VGPRs), round constants and MDS matrix read
-// through wave-uniform (scalar) loads from a 6.5 KB table. Integer-VALU-bound like everything else on this path:
-// 65 rounds = 8 x (3 S-boxes + 9 MDS products) + 57 x (1 S-box + 9) = 828 Montgomery products per hash (+3 for the
-// form changes); 64 B in / 32 B out per hash is nowhere near HBM-bound. A level of the tree is one launch.
+// Device mapping: one hash per lane, the 3-element state in registers (24 VGPRs), round constants and matrices read
+// through wave-uniform (scalar) loads from a 14 KB table. Integer-VALU-bound like everything else on this path; 64 B
+// in / 32 B out per hash is nowhere near HBM-bound. A level of the tree is one launch.
+//
+// The 57 partial rounds run in the equivalent sparse form of the Poseidon paper (appendix B; the form circomlib's own
+// poseidon_opt uses): round constants of the partial rounds are pushed through the inverse MDS matrix so that only the
+// S-box lane carries one, and the MDS product is factored into one dense 2 x 2 product up front plus, per round, a
+// matrix with a full first row, a full first column and an identity block -- 5 products instead of 9. A hash is
+// 8 x (9 + 9) + 4 + 57 x (3 + 5) = 604 Montgomery products (+3 for the form changes) instead of 828. The tables are
+// derived on the host from the plain parameters (host_params); zkpoa_poseidon_params still exports the plain ones,
+// and the parity tests compare the device hashes with the oracle's textbook permutation.
 #include "bn254_field.hip.h"
 #include "zkpoa_internal.hpp"
 
 #include <string.h>
 
+#include <array>
 #include <memory>
+#include <stdexcept>
+#include <utility>
 #include <vector>
 
 using namespace zkpoa;
@@ -26,9 +36,19 @@ namespace {
 
 constexpr int kT = 3, kRF = 8, kRP = 57, kRounds = kRF + kRP;
 
-struct PoseidonParams {   // Montgomery form, device layout
+struct PoseidonParams {   // Montgomery form; the textbook parameters (host side, zkpoa_poseidon_params)
   Fr C[kRounds * kT];
   Fr M[kT][kT];
+};
+
+struct PoseidonTables {   // Montgomery form, device layout: the sparse-partial-round form derived from PoseidonParams
+  Fr Cf[kRF][kT];         // constants of the 4 + 4 full rounds
+  Fr Cmid[kT];            // added once before the partial rounds
+  Fr Mhat[kT - 1][kT - 1];  // (s1, s2) <- (s1, s2) . Mhat before the partial rounds
+  Fr C0[kRP];             // constant of the S-box lane after the S-box of partial round r (the last one is zero)
+  Fr W[kRP][kT - 1];      // first row of round r's sparse matrix (without M00)
+  Fr V[kRP][kT - 1];      // first column
+  Fr M[kT][kT];           // MDS matrix (full rounds; M[0][0] also in the partial rounds)
 };
 
 // ---- parameter generation (host): generate_parameters_grain.sage 1 0 254 3 8 57 ------------------------------
@@ -117,6 +137,104 @@ void host_params(PoseidonParams& out) {
   }
 }
 
+// ---- the sparse form of the partial rounds (Poseidon paper, appendix B), derived on the host ---------------------
+// n x n inverse by Gauss-Jordan (n <= 3); throws on a singular matrix (cannot happen for an MDS matrix)
+template <int N>
+void mat_inv(const HFr (&a)[N][N], HFr (&out)[N][N]) {
+  HFr w[N][2 * N];
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      w[i][j] = a[i][j];
+      w[i][N + j] = i == j ? HFr::one() : HFr::zero();
+    }
+  for (int c = 0; c < N; c++) {
+    int p = c;
+    while (p < N && w[p][c].is_zero()) p++;
+    if (p == N) throw std::runtime_error("poseidon: singular matrix while deriving the sparse round form");
+    for (int j = 0; j < 2 * N; j++) std::swap(w[c][j], w[p][j]);
+    HFr iv = w[c][c].inv();
+    for (int j = 0; j < 2 * N; j++) w[c][j] = w[c][j] * iv;
+    for (int r = 0; r < N; r++) {
+      if (r == c || w[r][c].is_zero()) continue;
+      HFr f = w[r][c];
+      for (int j = 0; j < 2 * N; j++) w[r][j] = w[r][j] - f * w[c][j];
+    }
+  }
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) out[i][j] = w[i][N + j];
+}
+
+void host_tables(const PoseidonParams& plain, PoseidonTables& out) {
+  auto get = [](const Fr& f) {
+    HFr v;
+    memcpy(&v, &f, 32);
+    return v;
+  };
+  auto put = [](Fr& f, const HFr& v) { memcpy(&f, &v, 32); };
+  HFr M[kT][kT], MT[kT][kT], MTinv[kT][kT];
+  for (int i = 0; i < kT; i++)
+    for (int j = 0; j < kT; j++) {
+      M[i][j] = get(plain.M[i][j]);
+      MT[j][i] = M[i][j];
+    }
+  mat_inv<kT>(MT, MTinv);
+  // 1. constants: walking backwards over the partial rounds, c_(i+1) moves through M^-1 to the round before it;
+  //    only its S-box-lane component stays behind (to be added after that round's S-box)
+  std::vector<std::array<HFr, kT>> ct(kRounds);
+  for (int r = 0; r < kRounds; r++)
+    for (int i = 0; i < kT; i++) ct[r][i] = get(plain.C[r * kT + i]);
+  const int Rf = kRF / 2;
+  for (int i = kRounds - 2 - Rf; i >= Rf; i--) {
+    HFr moved[kT];   // row vector ct[i+1] times MT^-1
+    for (int j = 0; j < kT; j++) {
+      HFr acc = HFr::zero();
+      for (int k = 0; k < kT; k++) acc = acc + ct[i + 1][k] * MTinv[k][j];
+      moved[j] = acc;
+    }
+    for (int j = 1; j < kT; j++) ct[i][j] = ct[i][j] + moved[j];
+    ct[i + 1][0] = moved[0];
+    for (int j = 1; j < kT; j++) ct[i + 1][j] = HFr::zero();
+  }
+  // 2. matrices: M = M' . M'' with M'' sparse (first row, first column, identity block), repeated from the last
+  //    partial round backwards; what is left over at the front is one dense (t-1) x (t-1) block
+  HFr Mmul[kT][kT], Mi[kT][kT];
+  for (int i = 0; i < kT; i++)
+    for (int j = 0; j < kT; j++) Mmul[i][j] = MT[i][j];
+  for (int j = kRP - 1; j >= 0; j--) {   // j counts the rounds from the back: tables are stored in execution order
+    HFr hat[kT - 1][kT - 1], hat_inv[kT - 1][kT - 1];
+    for (int a = 1; a < kT; a++)
+      for (int b = 1; b < kT; b++) hat[a - 1][b - 1] = Mmul[a][b];
+    mat_inv<kT - 1>(hat, hat_inv);
+    for (int a = 1; a < kT; a++) {
+      put(out.V[j][a - 1], Mmul[0][a]);
+      HFr acc = HFr::zero();   // (hat^-1 . w)[a-1], w = first column of Mmul below the corner
+      for (int b = 1; b < kT; b++) acc = acc + hat_inv[a - 1][b - 1] * Mmul[b][0];
+      put(out.W[j][a - 1], acc);
+    }
+    for (int a = 0; a < kT; a++)
+      for (int b = 0; b < kT; b++) Mi[a][b] = a == b ? HFr::one() : HFr::zero();
+    for (int a = 1; a < kT; a++)
+      for (int b = 1; b < kT; b++) Mi[a][b] = hat[a - 1][b - 1];
+    for (int a = 0; a < kT; a++)
+      for (int b = 0; b < kT; b++) {
+        HFr acc = HFr::zero();
+        for (int k = 0; k < kT; k++) acc = acc + MT[a][k] * Mi[k][b];
+        Mmul[a][b] = acc;
+      }
+  }
+  for (int a = 1; a < kT; a++)
+    for (int b = 1; b < kT; b++) put(out.Mhat[a - 1][b - 1], Mi[a][b]);
+  for (int k = 0; k < Rf; k++)
+    for (int i = 0; i < kT; i++) {
+      put(out.Cf[k][i], ct[k][i]);
+      put(out.Cf[Rf + k][i], ct[Rf + kRP + k][i]);
+    }
+  for (int i = 0; i < kT; i++) put(out.Cmid[i], ct[Rf][i]);
+  for (int r = 0; r < kRP; r++) put(out.C0[r], r < kRP - 1 ? ct[Rf + 1 + r][0] : HFr::zero());
+  for (int i = 0; i < kT; i++)
+    for (int j = 0; j < kT; j++) put(out.M[i][j], M[i][j]);
+}
+
 // ---- device ----------------------------------------------------------------------------------------------------
 ZK_DEV Fr pow5(const Fr& x) {
   Fr x2 = x.sqr();
@@ -124,31 +242,45 @@ ZK_DEV Fr pow5(const Fr& x) {
   return x4 * x;
 }
 
+ZK_DEV void full_round(const PoseidonTables* __restrict__ prm, int k, Fr& s0, Fr& s1, Fr& s2) {
+  s0 = pow5(s0 + prm->Cf[k][0]);
+  s1 = pow5(s1 + prm->Cf[k][1]);
+  s2 = pow5(s2 + prm->Cf[k][2]);
+  Fr n0 = prm->M[0][0] * s0 + prm->M[0][1] * s1 + prm->M[0][2] * s2;
+  Fr n1 = prm->M[1][0] * s0 + prm->M[1][1] * s1 + prm->M[1][2] * s2;
+  Fr n2 = prm->M[2][0] * s0 + prm->M[2][1] * s1 + prm->M[2][2] * s2;
+  s0 = n0;
+  s1 = n1;
+  s2 = n2;
+}
+
 // standard-form inputs -> standard-form hash
-ZK_DEV Fr poseidon2(const PoseidonParams* __restrict__ prm, const Fr& left, const Fr& right) {
+ZK_DEV Fr poseidon2(const PoseidonTables* __restrict__ prm, const Fr& left, const Fr& right) {
   Fr s0 = Fr::zero(), s1 = left.to_mont(), s2 = right.to_mont();
-  for (int r = 0; r < kRounds; r++) {
-    s0 = s0 + prm->C[r * kT + 0];
-    s1 = s1 + prm->C[r * kT + 1];
-    s2 = s2 + prm->C[r * kT + 2];
-    s0 = pow5(s0);
-    if (r < kRF / 2 || r >= kRF / 2 + kRP) {   // wave-uniform branch
-      s1 = pow5(s1);
-      s2 = pow5(s2);
-    }
-    Fr n0 = prm->M[0][0] * s0 + prm->M[0][1] * s1 + prm->M[0][2] * s2;
-    Fr n1 = prm->M[1][0] * s0 + prm->M[1][1] * s1 + prm->M[1][2] * s2;
-    Fr n2 = prm->M[2][0] * s0 + prm->M[2][1] * s1 + prm->M[2][2] * s2;
-    s0 = n0;
+  for (int k = 0; k < kRF / 2; k++) full_round(prm, k, s0, s1, s2);
+  s0 = s0 + prm->Cmid[0];
+  s1 = s1 + prm->Cmid[1];
+  s2 = s2 + prm->Cmid[2];
+  {
+    Fr n1 = s1 * prm->Mhat[0][0] + s2 * prm->Mhat[1][0];
+    Fr n2 = s1 * prm->Mhat[0][1] + s2 * prm->Mhat[1][1];
     s1 = n1;
     s2 = n2;
   }
+  for (int r = 0; r < kRP; r++) {
+    s0 = pow5(s0) + prm->C0[r];
+    Fr n0 = s0 * prm->M[0][0] + s1 * prm->W[r][0] + s2 * prm->W[r][1];
+    s1 = s1 + s0 * prm->V[r][0];
+    s2 = s2 + s0 * prm->V[r][1];
+    s0 = n0;
+  }
+  for (int k = kRF / 2; k < kRF; k++) full_round(prm, k, s0, s1, s2);
   return s0.from_mont();
 }
 
 // out[i] = H(left[i * stride], right[i * stride]) for i < n; elements are 32 B LE standard form.
 // stride 1: independent pairs (leaves: addresses / balances); stride 2 with right = left + 1: one tree level.
-__global__ __launch_bounds__(256) void poseidon2_kernel(const PoseidonParams* __restrict__ prm, const void* left,
+__global__ __launch_bounds__(256) void poseidon2_kernel(const PoseidonTables* __restrict__ prm, const void* left,
                                                         const void* right, uint64_t stride, uint64_t n, void* out) {
   uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -157,7 +289,7 @@ __global__ __launch_bounds__(256) void poseidon2_kernel(const PoseidonParams* __
   store_field(reinterpret_cast<char*>(out) + 32 * i, poseidon2(prm, l, r));
 }
 
-void launch_hash(hipStream_t st, const PoseidonParams* prm, const void* l, const void* r, uint64_t stride, uint64_t n,
+void launch_hash(hipStream_t st, const PoseidonTables* prm, const void* l, const void* r, uint64_t stride, uint64_t n,
                  void* out) {
   if (n)
     hipLaunchKernelGGL(poseidon2_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, prm, l, r, stride, n, out);
@@ -167,16 +299,18 @@ void launch_hash(hipStream_t st, const PoseidonParams* prm, const void* l, const
 
 // parameters live with the context (uploaded on first use)
 struct zkpoa_poseidon_state {
-  PoseidonParams* d = nullptr;
+  PoseidonTables* d = nullptr;
 };
 
-static const PoseidonParams* device_params(zkpoa_context* ctx) {
+static const PoseidonTables* device_params(zkpoa_context* ctx) {
   if (!ctx->poseidon) {
     std::unique_ptr<zkpoa_poseidon_state> s(new zkpoa_poseidon_state());
     std::unique_ptr<PoseidonParams> h(new PoseidonParams());
+    std::unique_ptr<PoseidonTables> tb(new PoseidonTables());
     host_params(*h);
-    ZK_HIP(hipMalloc(reinterpret_cast<void**>(&s->d), sizeof(PoseidonParams)));
-    ZK_HIP(hipMemcpy(s->d, h.get(), sizeof(PoseidonParams), hipMemcpyHostToDevice));
+    host_tables(*h, *tb);
+    ZK_HIP(hipMalloc(reinterpret_cast<void**>(&s->d), sizeof(PoseidonTables)));
+    ZK_HIP(hipMemcpy(s->d, tb.get(), sizeof(PoseidonTables), hipMemcpyHostToDevice));
     ctx->poseidon = s.release();
   }
   return ctx->poseidon->d;
@@ -256,7 +390,7 @@ extern "C" int zkpoa_merkle_build_device(zkpoa_context* ctx, const void* d_addre
   const uint64_t N = 1ull << k, nodes = 2 * N - 1;
   ZK_HIP(hipMalloc(&t->d_levels, nodes * 32));
   hipStream_t st = ctx->dev.lanes[0].stream;
-  const PoseidonParams* prm = device_params(ctx);
+  const PoseidonTables* prm = device_params(ctx);
   char* lv = reinterpret_cast<char*>(t->d_levels);
   try {
     ZK_HIP(hipEventRecord(ctx->ev_a[0], st));
