@@ -309,19 +309,15 @@ def prove_leg(env, k, steps, warmup, precompute=True):
     world, rank = env.world, env.rank
     # N > 1: ONE proof sharded over the N GPUs (strong scaling): same circuit on every rank, each rank
     # owns index range rank/N of the five MSMs; partial points are all-gathered over RCCL and summed.
-    circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True)
-    header = circ.key.header()
+    # Each rank generates ONLY its own part of the key (its index ranges of the point sections, with the split chain
+    # its cyclic H shard and its constraints' records: zkpoa_zkey_load_device_shard) and, like the single-GPU key,
+    # gets the fixed-base tables of what it holds -- 1/N of the memory.
     split = world > 1 and not args.replicated_chain and sharding.split_chain_supported(world, 1 << k)
-    xbufs = None
-    table_bytes = 0
-    if split:
-        # the H-scalar chain is split over the ranks too: rows c = rank (mod N), two all-to-alls per polynomial
-        circ.key.set_shard_split(rank, world)
-        xbufs = sharding.exchange_buffers(1 << k, world, env.dev)
-    elif world > 1:
-        circ.key.set_shard(rank, world)
-    elif precompute:
-        table_bytes = circ.key.precompute()      # resident key: fixed-base tables, once, outside the timed region
+    circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True,
+                            shard=(rank, world, split) if world > 1 else None)
+    header = circ.key.header()
+    xbufs = sharding.exchange_buffers(1 << k, world, env.dev) if split else None
+    table_bytes = circ.key.precompute() if precompute else 0     # once, outside the timed region
 
     def one_proof():
         if world == 1:

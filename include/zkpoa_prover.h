@@ -91,6 +91,18 @@ int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_publi
                            const void* d_A, const void* d_B1, const void* d_B2, const void* d_C, const void* d_H,
                            const void* d_coef_records, uint64_t n_coefs, const uint8_t header_points[448],
                            zkpoa_zkey** zkey);
+/* One rank's shard of a key whose sections are already in HBM (bench.py --gpus N generates only its own ranges of
+ * the synthetic key; a device-native zkey cache would hand over what it keeps per GPU). Same arguments, but with
+ * world > 1 the buffers hold only what zkpoa_zkey_load_shard / _load_shard_split would upload for this rank:
+ * d_A, d_B1, d_B2 the wires [lo, lo + cnt) of sections 5-7 and d_C the same split of section 8, where for n items
+ * lo = rank * (n / world) + min(rank, n % world), cnt = n / world + (rank < n % world); d_H that range of section 9,
+ * or with split != 0 the cyclic shard H[t * world + rank], t < domain / world (copied: the handle owns its copy);
+ * d_coef_records all n_coefs records, or with split != 0 at least those of the constraints c = rank (mod world)
+ * (others are ignored). The handle is a shard: zkpoa_prove_partials (+ the split stages) and zkpoa_prove_assemble. */
+int zkpoa_zkey_load_device_shard(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                                 uint64_t rank, uint64_t world, int split, const void* d_A, const void* d_B1,
+                                 const void* d_B2, const void* d_C, const void* d_H, const void* d_coef_records,
+                                 uint64_t n_coefs, const uint8_t header_points[448], zkpoa_zkey** zkey);
 /* d_witness: n_vars x 32 B standard form on the device (w[0] = 1). */
 int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d_witness,
                        const uint8_t* r_le, const uint8_t* s_le,
@@ -151,7 +163,10 @@ int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_recei
 /* Fixed-base tables for a resident key (zkpoa_msm_table_build applied to sections 9, 8 and the A / B queries, in
  * that order while they fit budget_bytes; 0 = half of the HBM free at the call). Later proves on the handle use
  * them; proofs are bit-identical with and without. groth16_prover_zkey_file's key cache does this by itself the
- * second time a key is used (env ZKPOA_PRECOMP=0 disables). used_bytes (optional) <- HBM taken by the tables. */
+ * second time a key is used (env ZKPOA_PRECOMP=0 disables). used_bytes (optional) <- HBM taken by the tables.
+ * A shard handle (zkpoa_zkey_load_shard*, _load_device_shard) gets the tables of its own ranges -- 1/world of the
+ * memory per GPU -- incl. the cyclic H shard of a split handle; a resident key re-pointed with zkpoa_zkey_set_shard*
+ * uses its tables only while its range is the whole array they were built from. */
 int zkpoa_zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t budget_bytes, uint64_t* used_bytes);
 
 /* The H-MSM scalars of the LAST prove on this key handle (joinABC output, groth16_prove.js; domain x 32 B standard

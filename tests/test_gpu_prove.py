@@ -595,6 +595,48 @@ def test_set_shard_split_on_resident_key(ctx, zk, log_domain, world):
         circ.close()
 
 
+@pytest.mark.parametrize("log_domain,world,split", [(14, 2, False), (14, 3, False), (14, 4, True), (18, 8, True),
+                                                     (16, 2, True)])
+def test_per_rank_generated_shards_equal_unsharded(ctx, zk, log_domain, world, split):
+    """bench.py --gpus N: every rank generates ONLY its own ranges of the synthetic key (index ranges of the point
+    sections, cyclic H shard, its constraints' records) and loads them with zkpoa_zkey_load_device_shard; the N
+    partial results must assemble into the proof of the whole key of the same seed."""
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    m = (1 << log_domain) - 3000
+    whole = SyntheticCircuit(zk, ctx, log_domain, m, n_public=2, seed=9, witness_like=True)
+    try:
+        want, _ = whole.prove(5, 7)
+        header = whole.key.header()
+    finally:
+        whole.close()
+    ranks = [SyntheticCircuit(zk, ctx, log_domain, m, n_public=2, seed=9, witness_like=True, shard=(r, world, split))
+             for r in range(world)]
+    try:
+        # a shard holds 1/world of every point section
+        assert all(abs(c.d_A.numel() - whole.d_A.numel() // world) <= 64 for c in ranks)
+        assert all(c.key.header() == header for c in ranks)
+        with pytest.raises(zk.ZkpoaError, match="shard"):
+            ranks[0].prove(5, 7)
+        if split:
+            assert all(c.d_recs.shape[0] < whole.d_recs.shape[0] // world + 8 for c in ranks)
+            keys = [c.key for c in ranks]
+            parts = _split_chain_partials(ctx, keys, world, 1 << log_domain, d_witness=ranks[0].d_witness.data_ptr())
+        else:
+            parts = [ctx.prove_partials_device(c.key, c.d_witness.data_ptr()) for c in ranks]
+        assert zk.prove_assemble(header, zk.sum_partials(parts), 5, 7) == want
+        # fixed-base tables of each shard's own ranges (incl. the cyclic H shard): same partial points, bit for bit
+        assert all(c.key.precompute() > 0 for c in ranks)
+        if split:
+            parts2 = _split_chain_partials(ctx, [c.key for c in ranks], world, 1 << log_domain,
+                                           d_witness=ranks[0].d_witness.data_ptr())
+        else:
+            parts2 = [ctx.prove_partials_device(c.key, c.d_witness.data_ptr()) for c in ranks]
+        assert parts2 == parts
+    finally:
+        for c in ranks:
+            c.close()
+
+
 # ---- edge cases of the domain -------------------------------------------------------------------------------
 def _setup_small(rng, nVars, nPublic, nCons):
     cons, w = g16.random_circuit(rng, nVars, nPublic, nCons)

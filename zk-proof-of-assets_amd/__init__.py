@@ -28,7 +28,7 @@ EXPORTS = [
     "groth16_prover", "groth16_prover_zkey_file",
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
-    "zkpoa_zkey_load_device", "zkpoa_prove_device",
+    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device",
     "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
@@ -123,6 +123,9 @@ def lib():
         L.zkpoa_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong,
                                   ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
         L.zkpoa_zkey_load_device.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint] + \
+            [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
+        L.zkpoa_zkey_load_device_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint,
+                                                   ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int] + \
             [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
         L.zkpoa_prove_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p,
                                          ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
@@ -351,6 +354,19 @@ class Context:
         self._check(lib().zkpoa_zkey_load_device(self._h, n_vars, n_public, log_domain, d_A, d_B1, d_B2, d_C, d_H,
                                                  d_coefs, n_coefs, bytes(header_points), ctypes.byref(key._h)),
                     "zkpoa_zkey_load_device")
+        return key
+
+    def load_zkey_device_shard(self, n_vars, n_public, log_domain, rank, world, split, d_A, d_B1, d_B2, d_C, d_H,
+                               d_coefs, n_coefs, header_points):
+        """Shard `rank` of `world` from device-resident sections that hold only this rank's ranges
+        (include/zkpoa_prover.h: zkpoa_zkey_load_device_shard); the caller keeps the buffers alive."""
+        key = ZKey.__new__(ZKey)
+        key._ctx = self
+        key._h = ctypes.c_void_p()
+        self._check(lib().zkpoa_zkey_load_device_shard(self._h, n_vars, n_public, log_domain, rank, world,
+                                                       1 if split else 0, d_A, d_B1, d_B2, d_C, d_H, d_coefs, n_coefs,
+                                                       bytes(header_points), ctypes.byref(key._h)),
+                    "zkpoa_zkey_load_device_shard")
         return key
 
     def load_zkey_shard(self, zkey_bytes, rank, world):

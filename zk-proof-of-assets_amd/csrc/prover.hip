@@ -158,6 +158,7 @@ struct zkpoa_zkey {
   // resident base array -- the compacted A / B queries, section 8, section 9. An MSM uses its table only when it
   // covers exactly that array (a re-pointed shard of a resident key falls back to the classic form).
   MsmTable *tA = nullptr, *tB1 = nullptr, *tB2 = nullptr, *tC = nullptr, *tH = nullptr;
+  bool tH_cyclic = false;     // tH was built from the cyclic shard dHs (split handles), not from dH
   uint64_t table_bytes = 0;
   uint64_t proofs_done = 0;   // groth16_prover_zkey_file's cache precomputes when a key is used a second time
   void release_tables() {
@@ -166,6 +167,7 @@ struct zkpoa_zkey {
       *t = nullptr;
     }
     table_bytes = 0;
+    tH_cyclic = false;
   }
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
@@ -653,7 +655,7 @@ bool split_h_partial(const zkpoa_zkey* zk) {
 // closes the critical path and section 8 is the largest G1 array; then the A query; the B query needs both its
 // G1 and G2 table (they share one bucket sort). Returns the bytes allocated.
 uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
-  if (zk->split_world > 1 || zk->csr_local) throw ProverError(PROVER_ERROR, "precompute: not for split shards");
+  const bool split = zk->split_world > 1;   // H table over the cyclic shard; A / B / C as for any shard
   ctx->dev.wait_lanes();
   ZK_HIP(hipDeviceSynchronize());
   zk->release_tables();
@@ -666,7 +668,8 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
   }
   const int force_c = ctx->opt_msm_c;
   auto fits = [&](uint64_t bytes) { return zk->table_bytes + bytes <= budget; };
-  const uint64_t nH = zk->dH ? zk->hcnt : 0, nC = zk->ccnt, nA = zk->qA.res, nB = zk->qB.res;
+  const uint64_t nH = split ? (zk->dHs ? (uint64_t)(zk->domain >> zk->split_log) : 0) : (zk->dH ? zk->hcnt : 0);
+  const uint64_t nC = zk->ccnt, nA = zk->qA.res, nB = zk->qB.res;
   // a table that does not fit after all (allocation failure) ends the list; the ones built so far stay
   auto build = [&](MsmTable** slot, bool g2, const void* bases, uint64_t n, int c) -> bool {
     try {
@@ -680,7 +683,10 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
     }
   };
   bool more = true;
-  if (more && nH && zk->hlo == zk->hbase && fits(msm_table_bytes_g1(nH, force_c))) more = build(&zk->tH, false, zk->dH, nH, force_c);
+  if (more && nH && (split || zk->hlo == zk->hbase) && fits(msm_table_bytes_g1(nH, force_c))) {
+    more = build(&zk->tH, false, split ? zk->dHs : zk->dH, nH, force_c);
+    zk->tH_cyclic = split && zk->tH;
+  }
   if (more && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, force_c))) more = build(&zk->tC, false, zk->dC, nC, force_c);
   if (more && nA && fits(msm_table_bytes_g1(nA, force_c))) more = build(&zk->tA, false, zk->qA.g1, nA, force_c);
   if (more && nB) {
@@ -847,14 +853,15 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
               zk->power, zk->d_abc);
     ZK_HIP(hipEventRecord(ctx->ev_b[5], l0.stream));
     if (stg && stg->prep_H) stg->prep_H();
-    const MsmTable* useH = (!split && zk->tH && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr;
+    const MsmTable* useH = split ? (zk->tH && zk->tH_cyclic ? zk->tH : nullptr)
+                                 : ((zk->tH && !zk->tH_cyclic && zk->hlo == zk->hbase && !split_h_partial(zk)) ? zk->tH : nullptr);
     const char* pH = split ? reinterpret_cast<const char*>(zk->dHs)
                            : reinterpret_cast<const char*>(zk->dH) + (zk->hlo - zk->hbase) * 64;
     if ((split ? (zk->dHs == nullptr) : (zk->hcnt && zk->dH == nullptr)))
       throw ProverError(PROVER_ERROR, "internal: H stage started before its inputs");
     if (split) {
       // the three stages left this rank's H scalars (odd-coset indices = rank mod G) in d_abc[0 .. n/G)
-      msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0]);
+      msm_run_g1(ctx, 0, pH, zk->d_abc, zk->domain >> zk->split_log, outH, msm_ms[0], useH);
       zk->h_ready = false;
     } else {
       msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0], useH);
@@ -1603,6 +1610,14 @@ extern "C" int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, 
     check_split(zkey, rank, world);
     hipStream_t st = ctx->dev.lanes[0].stream;
     const uint64_t cnt = zkey->domain / world;
+    if (zkey->tH_cyclic) {   // built from the cyclic shard that is replaced now
+      uint64_t info[4];
+      msm_table_info(zkey->tH, info);
+      zkey->table_bytes -= info[3] < zkey->table_bytes ? info[3] : zkey->table_bytes;
+      msm_table_release(zkey->tH);
+      zkey->tH = nullptr;
+      zkey->tH_cyclic = false;
+    }
     if (zkey->dHs) {
       ZK_HIP(hipFree(zkey->dHs));
       zkey->dHs = nullptr;
@@ -1790,17 +1805,20 @@ extern "C" int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey, const voi
   return PROVER_OK;
 }
 
-extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
-                                      const void* d_A, const void* d_B1, const void* d_B2, const void* d_C,
-                                      const void* d_H, const void* d_coef_records, uint64_t n_coefs,
-                                      const uint8_t header_points[448], zkpoa_zkey** out) {
-  if (!ctx || !out || !header_points) return PROVER_ERROR;
-  *out = nullptr;
+// Key (or one rank's shard of it) from sections already in HBM. world == 1: the whole key. world > 1: the point
+// buffers hold only this rank's index ranges (zkpoa_zkey::split: the ranges zkpoa_zkey_load_shard uploads); with
+// `split`, d_H is the cyclic shard H[t * world + rank] and the records are those of the constraints
+// c = rank (mod world) (records of other constraints are ignored).
+static zkpoa_zkey* zkey_load_device_impl(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                                         uint64_t rank, uint64_t world, bool split, const void* d_A, const void* d_B1,
+                                         const void* d_B2, const void* d_C, const void* d_H,
+                                         const void* d_coef_records, uint64_t n_coefs, const uint8_t header_points[448]) {
   std::unique_ptr<zkpoa_zkey> zk(new zkpoa_zkey());
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
     if (log_domain > 28 || n_vars == 0 || n_vars > (1ull << 28) || n_public + 1 > n_vars || n_coefs > 0xffffffffull)
       throw ProverError(PROVER_ERROR, "zkey_load_device: size out of range");
+    if (world == 0 || rank >= world) throw ProverError(PROVER_ERROR, "zkey shard: rank/world out of range");
     zk->nVars = (uint32_t)n_vars;
     zk->nPublic = (uint32_t)n_public;
     zk->power = log_domain;
@@ -1811,27 +1829,67 @@ extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint6
     zk->dB1 = const_cast<void*>(d_B1);
     zk->dB2 = const_cast<void*>(d_B2);
     zk->dC = const_cast<void*>(d_C);
-    zk->dH = const_cast<void*>(d_H);
     zk->alpha1 = h_affine_from_bytes<HFq>(header_points);
     zk->beta1 = h_affine_from_bytes<HFq>(header_points + 64);
     zk->beta2 = h_affine_from_bytes<HFq2>(header_points + 128);
     zk->delta1 = h_affine_from_bytes<HFq>(header_points + 256);
     zk->delta2 = h_affine_from_bytes<HFq2>(header_points + 320);
-    zk->set_full();
-    queries_compact(ctx, zk.get(), zk->nVars);
-    build_csr(ctx, zk.get(), d_coef_records);
+    zk->set_shard(rank, world);   // world == 1: the whole key
+    zk->wbase = zk->wlo;
+    zk->cbase = zk->clo;
+    zk->hbase = zk->hlo;
+    if (split) {
+      check_split(zk.get(), rank, world);
+      set_split(zk.get(), rank, world);
+      // the handle owns its cyclic H shard (release() frees it): a copy of the caller's, device to device
+      const size_t bytes = (size_t)(zk->domain / world) * 64;
+      ZK_HIP(hipMalloc(&zk->dHs, bytes));
+      ZK_HIP(hipMemcpy(zk->dHs, d_H, bytes, hipMemcpyDeviceToDevice));
+      zk->hlo = zk->hbase = 0;
+      zk->hcnt = 0;   // no contiguous H range on this handle
+    } else {
+      zk->dH = const_cast<void*>(d_H);
+    }
+    queries_compact(ctx, zk.get(), zk->wcnt);
+    build_csr(ctx, zk.get(), d_coef_records, split);
     ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power);
+    if (split) ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power - zk->split_log);
     ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));
-  } catch (const ProverError& e) {
+  } catch (...) {
     zk->release();
-    ctx->last_error = e.what();
-    return e.code;
-  } catch (const std::exception& e) {
-    zk->release();
-    ctx->last_error = e.what();
-    return PROVER_ERROR;
+    throw;
   }
-  *out = zk.release();
+  return zk.release();
+}
+
+extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                                      const void* d_A, const void* d_B1, const void* d_B2, const void* d_C,
+                                      const void* d_H, const void* d_coef_records, uint64_t n_coefs,
+                                      const uint8_t header_points[448], zkpoa_zkey** out) {
+  if (!ctx || !out || !header_points) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, 0, 1, false, d_A, d_B1, d_B2, d_C, d_H,
+                                 d_coef_records, n_coefs, header_points);
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_zkey_load_device_shard(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
+                                            uint64_t rank, uint64_t world, int split, const void* d_A,
+                                            const void* d_B1, const void* d_B2, const void* d_C, const void* d_H,
+                                            const void* d_coef_records, uint64_t n_coefs,
+                                            const uint8_t header_points[448], zkpoa_zkey** out) {
+  if (!ctx || !out || !header_points) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, rank, world, split != 0, d_A, d_B1, d_B2, d_C, d_H,
+                                 d_coef_records, n_coefs, header_points);
+  }
+  ZK_PROVER_CATCH(ctx)
   return PROVER_OK;
 }
 

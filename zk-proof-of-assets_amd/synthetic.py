@@ -66,9 +66,15 @@ def _mont_g2_generator():
 class SyntheticCircuit:
     """Device-resident synthetic proving key + witness with known discrete logs."""
 
-    def __init__(self, zk, ctx, log_domain, n_vars, n_public=1, seed=0x5EED0010, witness_like=False, device=None):
+    def __init__(self, zk, ctx, log_domain, n_vars, n_public=1, seed=0x5EED0010, witness_like=False, device=None,
+                 shard=None):
+        """shard = (rank, world, split): generate and keep only that rank's part of the key -- its index ranges of
+        the point sections (sharding.shard_range), with `split` the cyclic H shard and the coefficient records of its
+        own constraints -- and load it with zkpoa_zkey_load_device_shard. Same key as the unsharded circuit of the
+        same seed, so the N partial results add up to its proof. The witness is whole on every rank."""
         import numpy as np
         import torch
+        from .sharding import shard_range
         self.zk, self.ctx = zk, ctx
         self.k, self.n, self.m, self.n_public = log_domain, 1 << log_domain, n_vars, n_public
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -77,16 +83,27 @@ class SyntheticCircuit:
         self.hdr = {x: rng.randrange(1, 1 << 64) for x in ("alpha", "beta", "delta")}
         m, n = self.m, self.n
         nC = m - n_public - 1
-        self.d_A = torch.empty(m * 64, dtype=torch.uint8, device=dev)
-        self.d_B1 = torch.empty(m * 64, dtype=torch.uint8, device=dev)
-        self.d_B2 = torch.empty(m * 128, dtype=torch.uint8, device=dev)
-        self.d_C = torch.empty(max(nC, 1) * 64, dtype=torch.uint8, device=dev)
-        self.d_H = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-        ctx.gen_bases_g1_device(*self.par["A"], 0, m, self.d_A.data_ptr())
-        ctx.gen_bases_g1_device(*self.par["B"], 0, m, self.d_B1.data_ptr())
-        ctx.gen_bases_g2_device(*self.par["B"], 0, m, self.d_B2.data_ptr())
-        ctx.gen_bases_g1_device(*self.par["C"], 0, nC, self.d_C.data_ptr())
-        ctx.gen_bases_g1_device(*self.par["H"], 0, n, self.d_H.data_ptr())
+        rank, world, split = shard if shard is not None else (0, 1, False)
+        self.shard = (rank, world, bool(split)) if shard is not None else None
+        (wlo, whi), (clo, chi), (hlo, hhi) = (shard_range(x, rank, world) for x in (m, nC, n))
+        wcnt, ccnt, hcnt = whi - wlo, chi - clo, hhi - hlo
+        self.d_A = torch.empty(max(wcnt, 1) * 64, dtype=torch.uint8, device=dev)
+        self.d_B1 = torch.empty(max(wcnt, 1) * 64, dtype=torch.uint8, device=dev)
+        self.d_B2 = torch.empty(max(wcnt, 1) * 128, dtype=torch.uint8, device=dev)
+        self.d_C = torch.empty(max(ccnt, 1) * 64, dtype=torch.uint8, device=dev)
+        ctx.gen_bases_g1_device(*self.par["A"], wlo, wcnt, self.d_A.data_ptr())
+        ctx.gen_bases_g1_device(*self.par["B"], wlo, wcnt, self.d_B1.data_ptr())
+        ctx.gen_bases_g2_device(*self.par["B"], wlo, wcnt, self.d_B2.data_ptr())
+        ctx.gen_bases_g1_device(*self.par["C"], clo, ccnt, self.d_C.data_ptr())
+        if split:
+            # H[t * world + rank] = (a + rank * b + t * (world * b)) G: the same generator with shifted parameters
+            ha, hb = self.par["H"]
+            hcnt = n // world
+            self.d_H = torch.empty(hcnt * 64, dtype=torch.uint8, device=dev)
+            ctx.gen_bases_g1_device((ha + rank * hb) % R_MOD, (world * hb) % R_MOD, 0, hcnt, self.d_H.data_ptr())
+        else:
+            self.d_H = torch.empty(max(hcnt, 1) * 64, dtype=torch.uint8, device=dev)
+            ctx.gen_bases_g1_device(*self.par["H"], hlo, hcnt, self.d_H.data_ptr())
         # coefficient records: constraint c has A-terms (a_c, 1), (b_c, 1) and B-term (d_c, 1); then public rows
         n_cons = n - n_public - 1
         g = torch.Generator(device="cpu")
@@ -118,12 +135,17 @@ class SyntheticCircuit:
         in_a[:n_public + 1] = True
         in_b[sig[:, 2].long()] = True
         self.in_a, self.in_b = in_a.numpy(), in_b.numpy()
-        self.d_A.view(m, 64)[(~in_a).to(dev)] = 0
-        self.d_B1.view(m, 64)[(~in_b).to(dev)] = 0
-        self.d_B2.view(m, 128)[(~in_b).to(dev)] = 0
+        if wcnt:
+            self.d_A[:wcnt * 64].view(wcnt, 64)[(~in_a[wlo:wlo + wcnt]).to(dev)] = 0
+            self.d_B1[:wcnt * 64].view(wcnt, 64)[(~in_b[wlo:wlo + wcnt]).to(dev)] = 0
+            self.d_B2[:wcnt * 128].view(wcnt, 128)[(~in_b[wlo:wlo + wcnt]).to(dev)] = 0
         self.n_coef = n_coef
         self.recs_host = recs                              # [n_coef, 11] int32 == 44-byte records
-        self.d_recs = recs.to(dev)
+        if split:                                          # only the records of this rank's constraints go to HBM
+            mine = recs[(recs[:, 1] % world) == rank].contiguous()
+            self.d_recs, n_dev = mine.to(dev), mine.shape[0]
+        else:
+            self.d_recs, n_dev = recs.to(dev), n_coef
         # witness: w[0] = 1, rest uniform 252-bit (or witness-like: 55% bits, 35% < 2^64, 10% uniform)
         nr = np.random.default_rng(seed + 1)
         limbs = nr.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + nr.integers(0, 2, size=(m, 4), dtype=np.uint64)
@@ -140,9 +162,15 @@ class SyntheticCircuit:
         G1, G2 = _mont_g1_generator(), _mont_g2_generator()
         hp = (zk.g1_mul(G1, self.hdr["alpha"]) + zk.g1_mul(G1, self.hdr["beta"]) + zk.g2_mul(G2, self.hdr["beta"]) +
               zk.g1_mul(G1, self.hdr["delta"]) + zk.g2_mul(G2, self.hdr["delta"]))
-        self.key = ctx.load_zkey_device(m, n_public, log_domain, self.d_A.data_ptr(), self.d_B1.data_ptr(),
-                                        self.d_B2.data_ptr(), self.d_C.data_ptr(), self.d_H.data_ptr(),
-                                        self.d_recs.data_ptr(), n_coef, hp)
+        if shard is None:
+            self.key = ctx.load_zkey_device(m, n_public, log_domain, self.d_A.data_ptr(), self.d_B1.data_ptr(),
+                                            self.d_B2.data_ptr(), self.d_C.data_ptr(), self.d_H.data_ptr(),
+                                            self.d_recs.data_ptr(), n_coef, hp)
+        else:
+            self.key = ctx.load_zkey_device_shard(m, n_public, log_domain, rank, world, split, self.d_A.data_ptr(),
+                                                  self.d_B1.data_ptr(), self.d_B2.data_ptr(), self.d_C.data_ptr(),
+                                                  self.d_H.data_ptr(), self.d_recs.data_ptr(), n_dev, hp)
+        self.header_points = hp
         self._G1, self._G2 = G1, G2
 
     def coeff_section(self):
