@@ -60,15 +60,26 @@ inline XYZZ<HF> h_mul(const XYZZ<HF>& p, const uint64_t k[4]) {
 // Horner over the per-window sums of one MSM: result = sum_w 2^(c*w) * S[w]
 template <class HF>
 inline XYZZ<HF> h_combine_windows(const void* window_sums, uint32_t W, uint32_t c, uint32_t logS) {
-  // window_sums: per window the pair (U, V) of the device's bucket reduction; window sum = 2^logS * U + V
+  // window_sums: per window and group (0 = row sums, 1 = column sums) the logS + 1 per-bit totals T_b of the device's
+  // bucket reduction; weighted total = sum_b 2^b T_b, window sum = 2^logS * U(rows) + V(columns)
   constexpr size_t X = 4 * HostBytes<HF>::N;
+  const uint32_t nbits = logS + 1;
   const char* base = reinterpret_cast<const char*>(window_sums);
+  auto weighted = [&](uint32_t group) {
+    XYZZ<HF> t = XYZZ<HF>::inf();
+    for (int b = (int)nbits - 1; b >= 0; b--) {
+      t = xyzz_dbl(t);
+      XYZZ<HF> tb = h_xyzz_from_bytes<HF>(base + ((size_t)group * nbits + (uint32_t)b) * X);
+      xyzz_add(t, tb);
+    }
+    return t;
+  };
   XYZZ<HF> acc = XYZZ<HF>::inf();
   for (int w = (int)W - 1; w >= 0; w--) {
     for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
-    XYZZ<HF> u = h_xyzz_from_bytes<HF>(base + (size_t)(2 * w) * X);
+    XYZZ<HF> u = weighted(2u * (uint32_t)w);
     for (uint32_t k = 0; k < logS; k++) u = xyzz_dbl(u);
-    XYZZ<HF> v = h_xyzz_from_bytes<HF>(base + (size_t)(2 * w + 1) * X);
+    XYZZ<HF> v = weighted(2u * (uint32_t)w + 1u);
     xyzz_add(acc, u);
     xyzz_add(acc, v);
   }

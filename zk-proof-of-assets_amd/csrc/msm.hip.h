@@ -78,7 +78,8 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   p.merged = merged;
   int best_c = 4;
   double best = 1e300;
-  const double* density = merged ? nullptr : msm_density_hint();
+  const double* density = msm_density_hint();   // merged form: the width is the table's (force_c) at run time, but a
+                                                // table for witness scalars is SIZED with the density of a witness
   for (int c = 4; c <= (merged ? 25 : 22); c++) {
     double W = (double)msm_windows((uint32_t)c);
     double sets = merged ? 1.0 : W;
@@ -108,7 +109,7 @@ inline MsmPlan msm_make_plan(size_t n, int force_c = 0, bool for_g2 = false, boo
   // a sort whose result also feeds a G2 accumulation (the prover's B query) uses a quarter of that; buckets
   // longer than K0 continue in the partial-sum levels.
   const double dens_entries = density ? density[p.c] * (double)p.n : (double)p.n * p.W;
-  double avg = (merged ? (double)p.ne : dens_entries / p.W) / (double)p.Nb;
+  double avg = (merged ? dens_entries : dens_entries / p.W) / (double)p.Nb;
   uint32_t k0 = 32;
   while (k0 < 2 * avg && k0 < 256) k0 <<= 1;
   if (for_g2 && k0 > 32) k0 = k0 >= 128 ? k0 / 4 : 32;
@@ -464,20 +465,31 @@ static __global__ __launch_bounds__(256) void msm_accumN_kernel(const void* __re
 // ---- 5: bucket reduction ----------------------------------------------------------------------
 // Window sum = sum_b (b + 1) * B_b. With b = hi * S + lo (rows x S matrix of the window's buckets):
 //   sum_b (b + 1) B_b = S * sum_hi hi * R_hi + sum_lo (lo + 1) * C_lo,   R_hi = row sums, C_lo = column sums.
-// All 2 * Nb additions of the row / column sums are independent: 2^logParts threads per sum add `per` (8-16)
+// All 2 * Nb additions of the row / column sums are independent: 2^logParts threads per sum add `per` (1-16)
 // buckets each, then an LDS tree over the parts -- enough threads to fill the chip whatever the bucket count (a
-// fixed-base MSM at c = 20 has 2^19 buckets: 1536 sums x 64 parts), every thread a short chain. The weights are
-// <= max(logS, logRows) bits (double-and-add per sum), and the two weighted totals U = sum hi R_hi,
-// V = sum (lo+1) C_lo per bucket set go to the host, which forms 2^logS * U + V.
+// fixed-base MSM at c = 20 has 2^19 buckets: 1536 sums x 64 parts), every thread a short chain. The weighted totals
+// U = sum hi R_hi, V = sum (lo+1) C_lo are NOT formed by multiplying every sum by its weight (a double-and-add of up
+// to logS + 1 bits per thread: 2 (logS + 1) dependent group operations, ~10 us each on a lone wave): for every bit
+// b of the weight one LDS tree adds the sums whose weight has that bit (msm_bit_tree_sum_kernel, all bits in one
+// launch) and the host forms sum_b 2^b T_b -- half the group operations, and a dependent chain of 8 per 256 sums.
+// With one bucket set (fixed-base form) the whole reduction is latency: a single 2^21 witness MSM spent 0.62 ms in
+// it (sums 0.30 + weights 0.18 + trees 0.15) next to 0.46 ms of bucket accumulation; chains of <= 2 + 7 (sums, more
+// parts when the launch would not fill the chip) and 8 (trees) bring that to ~0.2 ms.
 // Every kernel below has ONE inlined call site per group operation (a loop whose operand comes from HBM first and
 // from LDS afterwards): no scratch memory, ~140 VGPRs, so these waves co-reside with the accumulation kernel's.
 // out[(w * 2 + grp) * E + idx]: grp 0 = R (idx = hi < rows), grp 1 = C (idx = lo < S); E >= max(rows, S).
 constexpr uint32_t kReduceMaxLogParts = 8;   // one sum per 256-thread workgroup at most
-inline uint32_t msm_reduce_log_parts(uint32_t logRows) {
+constexpr uint32_t kReduceMaxBits = 16;      // weight bits (logS + 1 <= 14 for c <= 26)
+inline uint32_t msm_reduce_log_parts(uint32_t logRows, uint32_t logS = 0, uint32_t sets = 0) {
   uint32_t lp = logRows > 3 ? logRows - 3 : 0;   // per = 8 column terms (16 row terms when S = 2 * rows)
   if (lp < 4) lp = logRows < 4 ? logRows : 4;
-  return lp > kReduceMaxLogParts ? kReduceMaxLogParts : lp;
+  if (lp > kReduceMaxLogParts) lp = kReduceMaxLogParts;
+  // few bucket sets (fixed-base form: one): shorter chains until the launch has 2^16 threads
+  const uint32_t cap = logRows < kReduceMaxLogParts ? logRows : kReduceMaxLogParts;
+  while (sets && lp < cap && (((uint64_t)sets * ((1ull << logRows) + (1ull << logS))) << lp) < (1ull << 16)) lp++;
+  return lp;
 }
+inline uint32_t msm_reduce_bits(uint32_t logS) { return logS + 1; }   // column weights go up to S = 2^logS
 
 template <class F>
 static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void* __restrict__ buckets, uint32_t W,
@@ -514,29 +526,28 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
   if (valid && part == 0) store_xyzz(out, ((size_t)w * 2u + (is_row ? 0u : 1u)) * E + idx, acc);
 }
 
-// X[(w*2+grp)*E + idx] <- weight * X[...]: weight = idx for row sums, idx + 1 for column sums; padding
-// entries (idx >= rows resp. S) become the neutral element. MSB-first double-and-add.
+// Y[(g * nbits + b) * S_out + blockIdx.x] = sum of the X[g * E + idx], idx in this block's 256, whose weight has bit b
+// (g = w * 2 + grp; weight = idx for row sums, idx + 1 for column sums, 0 for padding entries). LDS tree.
 template <class F>
-static __global__ __launch_bounds__(256) void msm_bucket_weight_kernel(void* __restrict__ X, uint32_t logS,
-                                                                       uint32_t logRows, uint32_t E, uint32_t total) {
-  uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= total) return;
-  uint32_t grp = (gid / E) & 1u, idx = gid % E;
-  uint32_t cnt = grp ? (1u << logS) : (1u << logRows);
-  uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
-  XYZZ<F> r = XYZZ<F>::inf();
-  if (k) {
-    const XYZZ<F> v = load_xyzz<F>(X, gid);
-    const XYZZ<F> none = XYZZ<F>::inf();
-    if (!v.is_inf()) {
-      int top = 31 - __builtin_clz(k);
-      for (int bit = top; bit >= 0; bit--) {   // r = 2 r (+ v): one doubling site, one addition site
-        r = xyzz_dbl(r);
-        xyzz_add(r, ((k >> bit) & 1u) ? v : none);
-      }
-    }
+static __global__ __launch_bounds__(256) void msm_bit_tree_sum_kernel(const void* __restrict__ X, uint32_t E,
+                                                                      uint32_t logS, uint32_t logRows, uint32_t nbits,
+                                                                      uint32_t S_out, void* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const uint32_t g = blockIdx.y / nbits, b = blockIdx.y % nbits, grp = g & 1u;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t cnt = grp ? (1u << logS) : (1u << logRows);
+  const uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
+  XYZZ<F> v = XYZZ<F>::inf();
+  if ((k >> b) & 1u) v = load_xyzz<F>(X, (size_t)g * E + idx);
+  for (uint32_t stride = 128; stride > 0; stride >>= 1) {
+    store_xyzz(lds_raw, threadIdx.x, v);
+    __syncthreads();
+    XYZZ<F> o = XYZZ<F>::inf();
+    if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
+    __syncthreads();
+    xyzz_add(v, o);
   }
-  store_xyzz(X, gid, r);
+  if (threadIdx.x == 0) store_xyzz(Y, (size_t)blockIdx.y * S_out + blockIdx.x, v);
 }
 
 // Y[w][blockIdx.x] = sum of X[w][blockIdx.x*256 .. +256) (S entries per window), LDS tree.
@@ -620,7 +631,7 @@ inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
   bytes += al256(p1 * MsmSizes<F>::kXyzz);            // P1
   bytes += al256(p2 * MsmSizes<F>::kXyzz);            // P2
   bytes += al256(2 * p.Wb * E * MsmSizes<F>::kXyzz);                    // X: row / column sums
-  bytes += al256(2 * p.Wb * ((E + 255) / 256) * MsmSizes<F>::kXyzz) * 2;  // tree-sum levels
+  bytes += al256(2 * p.Wb * msm_reduce_bits(p.logS) * ((E + 255) / 256) * MsmSizes<F>::kXyzz) * 2;  // tree-sum levels
   return bytes + (1 << 12);
 }
 
@@ -737,8 +748,9 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
 // Phase B on lane.stream for base array d_bases. `own_arena`: true when `sr` was produced on this lane
 // by the immediately preceding msm_sort_phase (the accumulation buffers are then taken after it);
 // false when `sr` lives on another lane (that lane's stream must have finished phase A): this lane's arena
-// is reset and only holds the accumulation buffers. On return window_sums_host = 2 W XYZZ: per window the
-// weighted row total U and column total V (window sum = 2^logS * U + V, formed by h_combine_windows).
+// is reset and only holds the accumulation buffers. On return window_sums_host = 2 W (logS + 1) XYZZ: per window
+// and group (rows, columns) the totals T_b of the sums whose weight has bit b; h_combine_windows forms
+// U = sum_b 2^b T_b (rows), V (columns) and the window sum 2^logS * U + V. Room for 2 * 64 * kReduceMaxBits points.
 template <class F>
 inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases, void* window_sums_host,
                             bool own_arena, float* accum_ms = nullptr) {
@@ -763,8 +775,9 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   const uint32_t groups = 2u * p.Wb;
   char* X = ws.take<char>((size_t)groups * E * MsmSizes<F>::kXyzz);
   const uint32_t S1 = (E + 255) / 256;
-  char* Y1 = ws.take<char>((size_t)(S1 * groups) * MsmSizes<F>::kXyzz);
-  char* Y2 = ws.take<char>((size_t)(S1 * groups) * MsmSizes<F>::kXyzz);
+  const uint32_t nbits = msm_reduce_bits(p.logS), sums = groups * nbits;   // per-bit totals of every group
+  char* Y1 = ws.take<char>((size_t)(S1 * sums) * MsmSizes<F>::kXyzz);
+  char* Y2 = ws.take<char>((size_t)(S1 * sums) * MsmSizes<F>::kXyzz);
 
   ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
   if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
@@ -797,34 +810,34 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
     std::swap(Pin, Pout);
     std::swap(cap_in, cap_out);
   }
-  // bucket reduction: row / column sums, weights, totals per (window, group)
+  // bucket reduction: row / column sums, then per (window, group, weight bit) the total of the sums with that bit
   {
-    uint32_t log_parts = msm_reduce_log_parts(p.logRows);
+    uint32_t log_parts = msm_reduce_log_parts(p.logRows, p.logS, p.Wb);
     uint64_t threads = ((uint64_t)p.Wb << log_parts) * ((1u << p.logRows) + E);
     hipLaunchKernelGGL((msm_bucket_sums_kernel<F>), dim3((uint32_t)((threads + 255) / 256)), dim3(256),
                        256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.Wb, p.Nb, p.logS, p.logRows, log_parts, E,
                        (void*)X);
-    uint32_t total = groups * E;
-    hipLaunchKernelGGL((msm_bucket_weight_kernel<F>), dim3((total + 255) / 256), dim3(256), 0, st, (void*)X, p.logS,
-                       p.logRows, E, total);
   }
-  const char* cur = X;
-  uint32_t S = E;
   char* ybuf[2] = {Y1, Y2};
   int yi = 0;
-  while (true) {
+  uint32_t S = S1;
+  hipLaunchKernelGGL((msm_bit_tree_sum_kernel<F>), dim3(S1, sums), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+                     (const void*)X, E, p.logS, p.logRows, nbits, S1, (void*)ybuf[yi]);
+  const char* cur = ybuf[yi];
+  yi ^= 1;
+  while (S > 1) {
     uint32_t S_out = (S + 255) / 256;
-    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, groups), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, sums), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
                        (const void*)cur, S, S_out, (void*)ybuf[yi]);
     cur = ybuf[yi];
     yi ^= 1;
     S = S_out;
-    if (S == 1) break;
   }
-  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)groups * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
+  if ((size_t)sums * MsmSizes<F>::kXyzz > lane.pinned_cap) throw HipError("msm: read-back larger than the pinned staging area");
+  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)sums * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
   ZK_HIP(hipStreamSynchronize(st));
   ZK_HIP(hipGetLastError());
-  memcpy(window_sums_host, lane.pinned, (size_t)groups * MsmSizes<F>::kXyzz);
+  memcpy(window_sums_host, lane.pinned, (size_t)sums * MsmSizes<F>::kXyzz);
   if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));
 }
 

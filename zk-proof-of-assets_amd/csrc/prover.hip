@@ -160,6 +160,11 @@ struct zkpoa_zkey {
   MsmTable *tA = nullptr, *tB1 = nullptr, *tB2 = nullptr, *tC = nullptr, *tH = nullptr;
   bool tH_cyclic = false;     // tH was built from the cyclic shard dHs (split handles), not from dH
   uint64_t table_bytes = 0;
+  // digit density of the last witness measured on this handle (msm_density: non-zero digits per scalar for every
+  // window width). A circuit's witnesses all look alike (bits stay bits), so it is measured by the first proof only
+  // and sizes the windows of later proofs and of the witness tables (zkey_precompute after a proof).
+  mutable double witness_density[32];
+  mutable bool have_density = false;
   uint64_t proofs_done = 0;   // groth16_prover_zkey_file's cache precomputes when a key is used a second time
   void release_tables() {
     for (MsmTable** t : {&tA, &tB1, &tB2, &tC, &tH}) {
@@ -682,16 +687,27 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
       return false;
     }
   };
+  // H scalars are uniform; the A / B / C tables are sized for witness scalars when a proof has measured some
+  auto witness_c = [&](uint64_t n, bool g2) {
+    if (const char* e = getenv("ZKPOA_WITNESS_TABLE_C"))   // experiments only
+      if (atoi(e) >= 4 && atoi(e) <= 25) return atoi(e);
+    msm_set_density_hint(zk->have_density ? zk->witness_density : nullptr);
+    const int c = (int)msm_table_width(n, force_c, g2);
+    msm_set_density_hint(nullptr);
+    return c;
+  };
+  msm_set_density_hint(nullptr);
   bool more = true;
   if (more && nH && (split || zk->hlo == zk->hbase) && fits(msm_table_bytes_g1(nH, force_c))) {
     more = build(&zk->tH, false, split ? zk->dHs : zk->dH, nH, force_c);
     zk->tH_cyclic = split && zk->tH;
   }
-  if (more && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, force_c))) more = build(&zk->tC, false, zk->dC, nC, force_c);
-  if (more && nA && fits(msm_table_bytes_g1(nA, force_c))) more = build(&zk->tA, false, zk->qA.g1, nA, force_c);
+  const int cC = nC ? witness_c(nC, false) : 0, cA = nA ? witness_c(nA, false) : 0;
+  if (more && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, cC))) more = build(&zk->tC, false, zk->dC, nC, cC);
+  if (more && nA && fits(msm_table_bytes_g1(nA, cA))) more = build(&zk->tA, false, zk->qA.g1, nA, cA);
   if (more && nB) {
     // one window width for both B tables: the G2 model's (shorter pieces), as the shared sort is planned for G2
-    const int cB = (int)msm_table_width(nB, force_c, true);
+    const int cB = witness_c(nB, true);
     if (fits(msm_table_bytes_g1(nB, cB) + msm_table_bytes_g2(nB, cB))) {
       more = build(&zk->tB1, false, zk->qB.g1, nB, cB) && build(&zk->tB2, true, zk->qB.g2, nB, cB);
       if (!more && zk->tB1) {   // the pair is only usable together
@@ -753,17 +769,16 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   // digit density of this proof's witness (non-zero digits per scalar for every window width), measured once by the
   // first witness stage that gets there, on its own lane; the classic-form witness MSMs size their windows with it
   std::once_flag density_once;
-  double density[32];
-  bool density_ok = false;
   auto with_density = [&](int lane_id) -> const double* {
     const char* nd = getenv("ZKPOA_NO_DENSITY");
     if ((nd && *nd && strcmp(nd, "0") != 0) || !zk->d_flag || !zk->d_witness) return nullptr;
     std::call_once(density_once, [&] {
-      msm_density(ctx->dev.lanes[lane_id].stream, zk->d_witness, zk->nVars, density,
+      if (zk->have_density) return;
+      msm_density(ctx->dev.lanes[lane_id].stream, zk->d_witness, zk->nVars, zk->witness_density,
                   reinterpret_cast<char*>(zk->d_flag) + 256);
-      density_ok = true;
+      zk->have_density = true;
     });
-    return density_ok ? density : nullptr;
+    return zk->have_density ? zk->witness_density : nullptr;
   };
   auto gather = [&](int lane_id, const zkpoa_zkey::CompactQuery& q) {
     if (q.cnt)
