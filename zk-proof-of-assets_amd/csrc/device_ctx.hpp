@@ -64,7 +64,12 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   hipStream_t stream = nullptr;
   Arena ws;
   void* pinned = nullptr;
+  void* pinned_dev = nullptr;   // the same memory as kernels address it (read-backs are written by a kernel, not copied)
   size_t pinned_cap = 0;
+  // host copy of an MSM's read-back (the per-bit totals of its bucket reduction), owned by the lane: a fresh
+  // 256 KB buffer per call would be an mmap + munmap each time, and unmapping is slow in a process whose address
+  // space the GPU driver watches (measured: 11 % of the six-in-flight 2^20 MSM rate)
+  std::vector<char> host_sums;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // level 2 = highest, 1 = middle, 0 = lowest stream priority
   void init(int level = 0) {
@@ -75,6 +80,8 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
     ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio));
     pinned_cap = 1 << 20;
     ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
+    ZK_HIP(hipHostGetDevicePointer(&pinned_dev, pinned, 0));
+    host_sums.assign(pinned_cap, 0);
     ZK_HIP(hipEventCreate(&ev0));
     ZK_HIP(hipEventCreate(&ev1));
   }

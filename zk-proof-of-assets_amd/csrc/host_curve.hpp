@@ -57,31 +57,31 @@ inline XYZZ<HF> h_mul(const XYZZ<HF>& p, const uint64_t k[4]) {
   return r;
 }
 
-// Horner over the per-window sums of one MSM: result = sum_w 2^(c*w) * S[w]
+// result = sum_w 2^(c*w) * S[w] from the device's bucket reduction: per window and group (0 = row sums, 1 = column
+// sums) the logS + 1 per-bit totals T_b; weighted total = sum_b 2^b T_b, window sum S[w] = 2^logS * U(rows) + V(columns).
+// Every total has one power of two, e = c*w + (rows ? logS : 0) + b: ONE Horner pass over e (<= 254 + 2 logS
+// doublings and one addition per total; nested Horners per group and per window cost twice the doublings).
 template <class HF>
 inline XYZZ<HF> h_combine_windows(const void* window_sums, uint32_t W, uint32_t c, uint32_t logS) {
-  // window_sums: per window and group (0 = row sums, 1 = column sums) the logS + 1 per-bit totals T_b of the device's
-  // bucket reduction; weighted total = sum_b 2^b T_b, window sum = 2^logS * U(rows) + V(columns)
   constexpr size_t X = 4 * HostBytes<HF>::N;
   const uint32_t nbits = logS + 1;
   const char* base = reinterpret_cast<const char*>(window_sums);
-  auto weighted = [&](uint32_t group) {
-    XYZZ<HF> t = XYZZ<HF>::inf();
-    for (int b = (int)nbits - 1; b >= 0; b--) {
-      t = xyzz_dbl(t);
-      XYZZ<HF> tb = h_xyzz_from_bytes<HF>(base + ((size_t)group * nbits + (uint32_t)b) * X);
-      xyzz_add(t, tb);
-    }
-    return t;
-  };
+  const uint32_t top = c * (W ? W - 1 : 0) + 2 * logS;   // largest exponent that occurs
   XYZZ<HF> acc = XYZZ<HF>::inf();
-  for (int w = (int)W - 1; w >= 0; w--) {
-    for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
-    XYZZ<HF> u = weighted(2u * (uint32_t)w);
-    for (uint32_t k = 0; k < logS; k++) u = xyzz_dbl(u);
-    XYZZ<HF> v = weighted(2u * (uint32_t)w + 1u);
-    xyzz_add(acc, u);
-    xyzz_add(acc, v);
+  for (int e = (int)top; e >= 0; e--) {
+    acc = xyzz_dbl(acc);
+    // totals with exponent e: window w, rows with b = e - c*w - logS, columns with b = e - c*w
+    for (uint32_t w = 0; w < W && c * w <= (uint32_t)e; w++) {
+      const uint32_t rel = (uint32_t)e - c * w;
+      if (rel < nbits) {
+        XYZZ<HF> t = h_xyzz_from_bytes<HF>(base + ((size_t)(2 * w + 1) * nbits + rel) * X);
+        xyzz_add(acc, t);
+      }
+      if (rel >= logS && rel - logS < nbits) {
+        XYZZ<HF> t = h_xyzz_from_bytes<HF>(base + ((size_t)(2 * w) * nbits + (rel - logS)) * X);
+        xyzz_add(acc, t);
+      }
+    }
   }
   return acc;
 }

@@ -527,44 +527,57 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
 }
 
 // Y[(g * nbits + b) * S_out + blockIdx.x] = sum of the X[g * E + idx], idx in this block's 256, whose weight has bit b
-// (g = w * 2 + grp; weight = idx for row sums, idx + 1 for column sums, 0 for padding entries). LDS tree.
+// (g = w * 2 + grp; weight = idx for row sums, idx + 1 for column sums, 0 for padding entries).
+// ONE wave per workgroup: each lane adds its 4 entries, then 6 LDS tree levels. (A 256-thread workgroup would park
+// three of its four waves at the barriers for the whole tree -- and a parked wave holds its ~140 VGPRs, i.e. one of the
+// three slots per SIMD the accumulation kernels of the other MSMs in flight live on: with 288 such workgroups per
+// 2^20 MSM that cost 11 % of the six-in-flight rate.)
 template <class F>
-static __global__ __launch_bounds__(256) void msm_bit_tree_sum_kernel(const void* __restrict__ X, uint32_t E,
-                                                                      uint32_t logS, uint32_t logRows, uint32_t nbits,
-                                                                      uint32_t S_out, void* __restrict__ Y) {
+static __global__ __launch_bounds__(64) void msm_bit_tree_sum_kernel(const void* __restrict__ X, uint32_t E,
+                                                                     uint32_t logS, uint32_t logRows, uint32_t nbits,
+                                                                     uint32_t S_out, void* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const uint32_t g = blockIdx.y / nbits, b = blockIdx.y % nbits, grp = g & 1u;
-  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   const uint32_t cnt = grp ? (1u << logS) : (1u << logRows);
-  const uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
   XYZZ<F> v = XYZZ<F>::inf();
-  if ((k >> b) & 1u) v = load_xyzz<F>(X, (size_t)g * E + idx);
-  for (uint32_t stride = 128; stride > 0; stride >>= 1) {
-    store_xyzz(lds_raw, threadIdx.x, v);
-    __syncthreads();
+  // iterations 0..3: this lane's entries from HBM; 4..9: tree levels through LDS (one inlined addition site)
+  for (uint32_t it = 0; it < 10; it++) {
     XYZZ<F> o = XYZZ<F>::inf();
-    if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
-    __syncthreads();
+    if (it < 4) {
+      const uint32_t idx = blockIdx.x * 256u + it * 64u + threadIdx.x;
+      const uint32_t k = idx < cnt ? (grp ? idx + 1u : idx) : 0u;
+      if ((k >> b) & 1u) o = load_xyzz<F>(X, (size_t)g * E + idx);
+    } else {
+      const uint32_t stride = 32u >> (it - 4);
+      store_xyzz(lds_raw, threadIdx.x, v);
+      __syncthreads();
+      if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
+      __syncthreads();
+    }
     xyzz_add(v, o);
   }
   if (threadIdx.x == 0) store_xyzz(Y, (size_t)blockIdx.y * S_out + blockIdx.x, v);
 }
 
-// Y[w][blockIdx.x] = sum of X[w][blockIdx.x*256 .. +256) (S entries per window), LDS tree.
+// Y[w][blockIdx.x] = sum of X[w][blockIdx.x*256 .. +256) (S entries per window); same one-wave shape.
 template <class F>
-static __global__ __launch_bounds__(256) void msm_tree_sum_kernel(const void* __restrict__ X, uint32_t S, uint32_t S_out,
+static __global__ __launch_bounds__(64) void msm_tree_sum_kernel(const void* __restrict__ X, uint32_t S, uint32_t S_out,
                                                            void* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  uint32_t w = blockIdx.y;
-  uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t w = blockIdx.y;
   XYZZ<F> v = XYZZ<F>::inf();
-  if (idx < S) v = load_xyzz<F>(X, (size_t)w * S + idx);
-  for (uint32_t stride = 128; stride > 0; stride >>= 1) {
-    store_xyzz(lds_raw, threadIdx.x, v);
-    __syncthreads();
+  for (uint32_t it = 0; it < 10; it++) {
     XYZZ<F> o = XYZZ<F>::inf();
-    if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
-    __syncthreads();
+    if (it < 4) {
+      const uint32_t idx = blockIdx.x * 256u + it * 64u + threadIdx.x;
+      if (idx < S) o = load_xyzz<F>(X, (size_t)w * S + idx);
+    } else {
+      const uint32_t stride = 32u >> (it - 4);
+      store_xyzz(lds_raw, threadIdx.x, v);
+      __syncthreads();
+      if (threadIdx.x < stride) o = load_xyzz<F>(lds_raw, threadIdx.x + stride);
+      __syncthreads();
+    }
     xyzz_add(v, o);
   }
   if (threadIdx.x == 0) store_xyzz(Y, (size_t)w * S_out + blockIdx.x, v);
@@ -576,6 +589,22 @@ struct MsmSizes {
   static constexpr size_t kAffine = 2 * FieldBytes<F>::N;
   static constexpr size_t kXyzz = 4 * FieldBytes<F>::N;
 };
+
+// Read-back of a few bytes to KB: a kernel stores them into the lane's pinned host buffer. (hipMemcpyAsync device ->
+// host goes through the SDMA engine: measured ~0.15 ms per MSM for the 37 KB of per-bit totals with six MSMs in
+// flight -- 8 % of the 2^20 rate -- and HSA_ENABLE_SDMA=0 is not ours to set for the caller's process.)
+static __global__ __launch_bounds__(256) void msm_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                                 uint32_t n16) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+inline void msm_read_back(Lane& lane, const void* d_src, size_t bytes) {
+  if (bytes > lane.pinned_cap) throw HipError("msm: read-back larger than the pinned staging area");
+  const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+  const uint32_t grid = n16 > 4096 ? 16u : (n16 + 255) / 256;
+  hipLaunchKernelGGL(msm_to_host_kernel, dim3(grid ? grid : 1), dim3(256), 0, lane.stream, (const uint4*)d_src,
+                     (uint4*)lane.pinned_dev, n16);
+  ZK_HIP(hipStreamSynchronize(lane.stream));
+}
 
 // ---- host driver: two phases ---------------------------------------------------------------------
 // Phase A (scalars only): digits, bucket sort, scans, piece ordering. Its result can serve several
@@ -730,8 +759,7 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
     }
   }
   uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
-  ZK_HIP(hipMemcpyAsync(hb, misc, 16, hipMemcpyDeviceToHost, st));
-  ZK_HIP(hipStreamSynchronize(st));
+  msm_read_back(lane, misc, 16);
   sr.max_count = hb[1];
   sr.total1 = hb[2];
   if (sr.total1) {
@@ -821,21 +849,19 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   char* ybuf[2] = {Y1, Y2};
   int yi = 0;
   uint32_t S = S1;
-  hipLaunchKernelGGL((msm_bit_tree_sum_kernel<F>), dim3(S1, sums), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+  hipLaunchKernelGGL((msm_bit_tree_sum_kernel<F>), dim3(S1, sums), dim3(64), 64 * MsmSizes<F>::kXyzz, st,
                      (const void*)X, E, p.logS, p.logRows, nbits, S1, (void*)ybuf[yi]);
   const char* cur = ybuf[yi];
   yi ^= 1;
   while (S > 1) {
     uint32_t S_out = (S + 255) / 256;
-    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, sums), dim3(256), 256 * MsmSizes<F>::kXyzz, st,
+    hipLaunchKernelGGL((msm_tree_sum_kernel<F>), dim3(S_out, sums), dim3(64), 64 * MsmSizes<F>::kXyzz, st,
                        (const void*)cur, S, S_out, (void*)ybuf[yi]);
     cur = ybuf[yi];
     yi ^= 1;
     S = S_out;
   }
-  if ((size_t)sums * MsmSizes<F>::kXyzz > lane.pinned_cap) throw HipError("msm: read-back larger than the pinned staging area");
-  ZK_HIP(hipMemcpyAsync(lane.pinned, cur, (size_t)sums * MsmSizes<F>::kXyzz, hipMemcpyDeviceToHost, st));
-  ZK_HIP(hipStreamSynchronize(st));
+  msm_read_back(lane, cur, (size_t)sums * MsmSizes<F>::kXyzz);
   ZK_HIP(hipGetLastError());
   memcpy(window_sums_host, lane.pinned, (size_t)sums * MsmSizes<F>::kXyzz);
   if (accum_ms) ZK_HIP(hipEventElapsedTime(accum_ms, lane.ev0, lane.ev1));

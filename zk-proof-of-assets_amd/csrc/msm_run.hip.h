@@ -14,7 +14,7 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   if (lane_id) ctx->dev.wait_lanes();
   ctx->dev.ensure_lane(lane_id);
   Lane& lane = ctx->dev.lanes[lane_id];
-  std::vector<char> wsums((size_t)64 * 2 * kReduceMaxBits * MsmSizes<F>::kXyzz);
+  std::vector<char>& wsums = lane.host_sums;   // room for the largest read-back (msm_accum_phase checks it)
   const uint64_t max_pts = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
   if (table && (n > max_pts || table->n != n)) table = nullptr;   // a chunked MSM cannot index a whole-array table
   XYZZ<HF> total = XYZZ<HF>::inf();
@@ -52,7 +52,7 @@ void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool ow
                    uint8_t* out, float* ms2) {
   if (lane_id) ctx->dev.wait_lanes();
   Lane& lane = ctx->dev.lanes[lane_id];
-  std::vector<char> wsums((size_t)64 * 2 * kReduceMaxBits * MsmSizes<F>::kXyzz);
+  std::vector<char>& wsums = lane.host_sums;
   float acc_ms = 0;
   ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
   msm_accum_phase<F>(lane, sr, d_bases, wsums.data(), own_arena, &acc_ms);

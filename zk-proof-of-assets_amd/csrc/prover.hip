@@ -882,7 +882,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
       msm_run_g1(ctx, 0, pH, reinterpret_cast<const char*>(zk->d_abc) + zk->hlo * 32, zk->hcnt, outH, msm_ms[0], useH);
     }
     ZK_HIP(hipEventElapsedTime(&ctx->ms[3], ctx->ev_a[5], ctx->ev_b[5]));
-    ZK_HIP(hipMemcpy(&witness_bad, zk->d_flag, 4, hipMemcpyDeviceToHost));   // lane 0 is idle: its MSM has returned
+    msm_read_back(l0, zk->d_flag, 4);   // lane 0 is idle (its MSM has returned): the flag through its pinned buffer
+    witness_bad = *reinterpret_cast<const uint32_t*>(l0.pinned);
   } catch (...) {
     main_err = std::current_exception();
   }
