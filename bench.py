@@ -421,7 +421,7 @@ def prove_leg(env, k, steps, warmup, precompute=True):
                        "fixed_base_tables_GB": table_bytes / 1e9,
                        "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
                                        "points; H-scalar chain %s" % (world, "split (four-step NTTs, 2 all-to-alls per "
-                                       "polynomial)" if split else "replicated")) if world > 1 else "single GPU",
+                                       "proof, all three polynomials in each)" if split else "replicated")) if world > 1 else "single GPU",
                        "checked": checked},
             "roofline": roof,
         }
