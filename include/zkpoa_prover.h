@@ -235,6 +235,18 @@ int zkpoa_g2_sum(const void* points, uint64_t count, uint8_t out[128]);
 int zkpoa_g1_mul(const uint8_t point[64], const uint8_t scalar_le[32], uint8_t out[64]);
 int zkpoa_g2_mul(const uint8_t point[128], const uint8_t scalar_le[32], uint8_t out[128]);
 
+/* ---- phase-2 setup arithmetic: the point sections of `snarkjs zkey new`, scripts/g16_setup.sh:243-246 ----
+ * out[s] = sum over the entries e with signal[e] == s of coefs[e] * points[point_index[e]], s < n_signals: one call per
+ * zkey section -- A (section 5): the A-matrix coefficients over the Lagrange-form tau*G1 points of the prepared .ptau;
+ * B1 / B2 (6, 7): the B matrix over tau*G1 resp. tau*G2; IC + C (3, 8): A over beta*tau*G1, B over alpha*tau*G1 and
+ * C over tau*G1 in one call (concatenate the three point arrays and offset the indices). Everything on the device:
+ * points in the zkey / ptau wire format (affine Montgomery, 64 B G1, 128 B G2; group = 1 | 2), coefs nnz x 32 B
+ * little-endian standard form (< r, as an .r1cs file stores them), indices u32; out n_signals points, wire format,
+ * signals without an entry = the point at infinity (all zero). Entries may come in any order. */
+int zkpoa_setup_accumulate(zkpoa_context* ctx, int group, const void* d_points, uint64_t n_points, const void* d_coefs,
+                           const uint32_t* d_point_index, const uint32_t* d_signal, uint64_t nnz, uint64_t n_signals,
+                           void* d_out);
+
 /* ---- the step after the path; host only, no GPU ----------------------------------------
  * zkpoa_groth16_verify: `npx snarkjs groth16 verify <vkey> <public> <proof>` (scripts/g16_verify.sh:213-216)
  *   on the three JSON texts. Returns PROVER_OK (valid), ZKPOA_VERIFY_INVALID_PROOF, or PROVER_ERROR (malformed).

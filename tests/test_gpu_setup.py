@@ -1,0 +1,106 @@
+"""Phase-2 setup arithmetic (csrc/setup.hip, C ABI zkpoa_setup_accumulate; `snarkjs zkey new`, g16_setup.sh:243-246):
+out[s] = sum over the entries of signal s of coef * point. The points are k_i * G with known k_i (the oracle's
+fixed-base products), so the expected output is (sum coef * k_i mod r) * G from the oracle -- bit-exact, G1 and G2,
+with the coefficient shapes an R1CS has (1, -1 = r - 1, small constants, powers of two, full-width), a hot signal
+(the constant-one wire), empty signals, single-entry signals, and the documented rejections."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import le
+from oracle import c_oracle as co
+from oracle.py import bn254 as bn
+
+pytestmark = pytest.mark.gpu
+R = bn.R
+
+
+def _dev(b):
+    import torch
+    return torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+
+
+def _coef(rng):
+    u = rng.random()
+    if u < 0.35: return 1
+    if u < 0.55: return R - 1
+    if u < 0.70: return rng.randrange(2, 1 << 16)
+    if u < 0.80: return 1 << rng.randrange(0, 253)
+    if u < 0.85: return R - (1 << rng.randrange(0, 200))
+    if u < 0.87: return 0
+    return rng.randrange(R)
+
+
+def _instance(rng, n_points, n_signals, nnz, hot=0.4):
+    ks = [rng.randrange(R) for _ in range(n_points)]
+    sig, pidx, coefs = [], [], []
+    used = list(range(0, n_signals, 1))
+    empties = set(rng.sample(used, max(1, n_signals // 7))) - {0} if n_signals > 3 else set()
+    cand = [s for s in used if s not in empties]
+    for _ in range(nnz):
+        s = 0 if rng.random() < hot else rng.choice(cand)
+        sig.append(s); pidx.append(rng.randrange(n_points)); coefs.append(_coef(rng))
+    want = [0] * n_signals
+    for s, i, c in zip(sig, pidx, coefs):
+        want[s] = (want[s] + c * ks[i]) % R
+    return ks, sig, pidx, coefs, want
+
+
+@pytest.mark.parametrize("group,n_points,n_signals,nnz", [(1, 1, 1, 1), (1, 50, 40, 0), (1, 700, 300, 4000),
+                                                          (1, 3000, 5000, 60000), (2, 200, 150, 1500),
+                                                          (2, 900, 1000, 9000)])
+def test_setup_accumulate_equals_oracle(ctx, group, n_points, n_signals, nnz):
+    import torch
+    rng = random.Random(77 * group + nnz)
+    size = 64 if group == 1 else 128
+    fb = co.fixed_base_g1 if group == 1 else co.fixed_base_g2
+    ks, sig, pidx, coefs, want = _instance(rng, n_points, n_signals, nnz)
+    pts = bytearray(fb(b"".join(le(k) for k in ks), 8))
+    if n_points > 10:                       # a point at infinity among the inputs (an unused Lagrange slot)
+        pts[size * 3:size * 4] = bytes(size)
+        for j, (s, i, c) in enumerate(zip(sig, pidx, coefs)):
+            if i == 3:
+                want[s] = (want[s] - c * ks[3]) % R
+    d_pts = _dev(pts)
+    d_coef = _dev(b"".join(le(c) for c in coefs) or b"\0")
+    d_pidx = torch.tensor(pidx or [0], dtype=torch.int64).to(torch.int32).cuda()
+    d_sig = torch.tensor(sig or [0], dtype=torch.int64).to(torch.int32).cuda()
+    d_out = torch.full((n_signals * size,), 0xAB, dtype=torch.uint8, device="cuda")
+    ctx.setup_accumulate(group, d_pts.data_ptr(), n_points, d_coef.data_ptr(), d_pidx.data_ptr(), d_sig.data_ptr(),
+                         nnz, n_signals, d_out.data_ptr())
+    got = d_out.cpu().numpy().tobytes()
+    assert got == fb(b"".join(le(w) for w in want), 8)
+    # same entries in another order: same bytes
+    if nnz > 1:
+        perm = list(range(nnz)); rng.shuffle(perm)
+        d_coef2 = _dev(b"".join(le(coefs[i]) for i in perm))
+        d_pidx2 = torch.tensor([pidx[i] for i in perm], dtype=torch.int64).to(torch.int32).cuda()
+        d_sig2 = torch.tensor([sig[i] for i in perm], dtype=torch.int64).to(torch.int32).cuda()
+        d_out2 = torch.zeros_like(d_out)
+        ctx.setup_accumulate(group, d_pts.data_ptr(), n_points, d_coef2.data_ptr(), d_pidx2.data_ptr(),
+                             d_sig2.data_ptr(), nnz, n_signals, d_out2.data_ptr())
+        assert d_out2.cpu().numpy().tobytes() == got
+
+
+def test_setup_accumulate_rejections(ctx, zk):
+    import torch
+    pts = _dev(co.fixed_base_g1(le(5) + le(7), 1))
+    out = torch.zeros(3 * 64, dtype=torch.uint8, device="cuda")
+    i32 = lambda vals: torch.tensor(vals, dtype=torch.int64).to(torch.int32).cuda()
+    ok_coef, bad_coef = _dev(le(1) + le(2)), _dev(le(1) + le(R))
+    i01, i02, i03 = i32([0, 1]), i32([0, 2]), i32([0, 3])      # kept alive: the calls take raw pointers
+
+    def call(group, coef, pidx, sig):
+        ctx.setup_accumulate(group, pts.data_ptr(), 2, coef.data_ptr(), pidx.data_ptr(), sig.data_ptr(), 2, 3,
+                             out.data_ptr())
+    call(1, ok_coef, i01, i01)
+    with pytest.raises(zk.ZkpoaError, match="out of range"):
+        call(1, ok_coef, i02, i01)            # point index 2 of 2 points
+    with pytest.raises(zk.ZkpoaError, match="out of range"):
+        call(1, ok_coef, i01, i03)            # signal 3 of 3 signals
+    with pytest.raises(zk.ZkpoaError, match="field element"):
+        call(1, bad_coef, i01, i01)           # coefficient r
+    with pytest.raises(zk.ZkpoaError, match="group"):
+        call(3, ok_coef, i01, i01)
+    call(1, ok_coef, i01, i01)                # the context is still usable
