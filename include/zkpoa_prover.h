@@ -246,6 +246,15 @@ int zkpoa_g2_mul(const uint8_t point[128], const uint8_t scalar_le[32], uint8_t 
 int zkpoa_setup_accumulate(zkpoa_context* ctx, int group, const void* d_points, uint64_t n_points, const void* d_coefs,
                            const uint32_t* d_point_index, const uint32_t* d_signal, uint64_t nnz, uint64_t n_signals,
                            void* d_out);
+/* `snarkjs zkey new <circuit.r1cs> <pot.ptau> <circuit_0.zkey>` (= `snarkjs groth16 setup`; g16_setup.sh:243-252) on
+ * files: reads the R1CS (iden3 binary format) and, from a .ptau prepared for phase 2, only the Lagrange-form point
+ * ranges of the circuit's domain; computes sections 3 and 5-8 with zkpoa_setup_accumulate, section 9 (H) as the odd
+ * points of the size-2n Lagrange basis, section 4 as snarkjs stores it (A and B terms per constraint ascending by
+ * signal, then the nPublic + 1 public rows; values scaled by R^2), header with gamma2 = delta2 = the G2 generator
+ * and delta1 = the G1 generator. Section 10 holds a zero circuit hash and no contributions: snarkjs' transcript hash
+ * is not restated (nothing in the reference pins it), so the key proves and verifies but `snarkjs zkey verify` would
+ * not accept its hash. The `zkpoa-setup` executable takes snarkjs' argument order. Errors: zkpoa_last_error. */
+int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path);
 
 /* ---- the step after the path; host only, no GPU ----------------------------------------
  * zkpoa_groth16_verify: `npx snarkjs groth16 verify <vkey> <public> <proof>` (scripts/g16_verify.sh:213-216)

@@ -104,3 +104,73 @@ def test_setup_accumulate_rejections(ctx, zk):
     with pytest.raises(zk.ZkpoaError, match="group"):
         call(3, ok_coef, i01, i01)
     call(1, ok_coef, i01, i01)                # the context is still usable
+
+
+# ---- `snarkjs zkey new` on files: zkpoa_zkey_new / the zkpoa-setup executable --------------------------------------
+def _setup_case(rng, n_vars, n_public, n_cons):
+    from oracle.py import groth16 as g16
+    from setup_files import write_ptau, write_r1cs
+    cons, w = g16.random_circuit(rng, n_vars, n_public, n_cons)
+    tox = {"tau": rng.randrange(2, R), "alpha": rng.randrange(2, R), "beta": rng.randrange(2, R), "gamma": 1, "delta": 1}
+    want, vk = g16.synthetic_setup(n_vars, n_public, cons, tox,
+                                   g1_batch=lambda s: co.fixed_base_g1(b"".join(le(k) for k in s), 8),
+                                   g2_batch=lambda s: co.fixed_base_g2(b"".join(le(k) for k in s), 8))
+    power = g16.read_zkey(want).domainSize.bit_length() - 1
+    return cons, w, tox, want, vk, write_r1cs(n_vars, n_public, cons), power
+
+
+@pytest.mark.parametrize("n_vars,n_public,n_cons,extra_power", [(12, 1, 5, 0), (40, 3, 60, 1), (300, 2, 500, 0),
+                                                               (2000, 0, 4000, 2)])
+def test_zkey_new_equals_the_setup_with_known_toxic_waste(ctx, zk, tmp_path, n_vars, n_public, n_cons, extra_power):
+    """r1cs + ptau files -> zkey, byte for byte the key that the oracle derives directly from tau, alpha, beta (delta =
+    gamma = 1, as `zkey new` leaves them); the key then proves (self-check against its own vkey on) and verifies."""
+    from oracle.py import groth16 as g16
+    from setup_files import write_ptau
+    rng = random.Random(n_vars * 31 + n_cons)
+    cons, w, tox, want, vk, r1cs, power = _setup_case(rng, n_vars, n_public, n_cons)
+    (tmp_path / "c.r1cs").write_bytes(r1cs)
+    (tmp_path / "pot.ptau").write_bytes(write_ptau(power + extra_power, tox["tau"], tox["alpha"], tox["beta"]))
+    ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "pot.ptau", tmp_path / "c_0.zkey")
+    got = (tmp_path / "c_0.zkey").read_bytes()
+    assert got == want
+    key = ctx.load_zkey(got)
+    try:
+        pts, pub = ctx.prove(key, g16.write_wtns(w), 11, 13)       # default self-check: first proof of a key
+        assert zk.groth16_verify_points(key.vkey_points(), pts, pub)
+    finally:
+        key.close()
+
+
+def test_zkpoa_setup_cli_and_rejections(ctx, zk, tmp_path):
+    import subprocess
+    from setup_files import write_ptau
+    rng = random.Random(5)
+    cons, w, tox, want, vk, r1cs, power = _setup_case(rng, 30, 2, 40)
+    (tmp_path / "c.r1cs").write_bytes(r1cs)
+    (tmp_path / "pot.ptau").write_bytes(write_ptau(power, tox["tau"], tox["alpha"], tox["beta"]))
+    for words in ([], ["zkey", "new"], ["groth16", "setup"]):
+        out = tmp_path / ("o%d.zkey" % len(words))
+        rc = subprocess.run([zk.SETUP_BIN] + words + ["c.r1cs", "pot.ptau", str(out)], cwd=tmp_path,
+                            capture_output=True, text=True, timeout=300)
+        assert rc.returncode == 0, rc.stderr
+        assert out.read_bytes() == want
+    # a ceremony too small for the circuit
+    (tmp_path / "small.ptau").write_bytes(write_ptau(power - 1, tox["tau"], tox["alpha"], tox["beta"]))
+    with pytest.raises(zk.ZkpoaError, match="too small"):
+        ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "small.ptau", tmp_path / "x.zkey")
+    # not an r1cs; a coefficient that is not a field element; a ptau that was not prepared for phase 2
+    (tmp_path / "bad.r1cs").write_bytes(b"r1cx" + r1cs[4:])
+    with pytest.raises(zk.ZkpoaError, match="magic"):
+        ctx.zkey_new(tmp_path / "bad.r1cs", tmp_path / "pot.ptau", tmp_path / "x.zkey")
+    i = r1cs.index(le(1), 100)
+    (tmp_path / "big.r1cs").write_bytes(r1cs[:i] + le(R) + r1cs[i + 32:])
+    with pytest.raises(zk.ZkpoaError, match="field element"):
+        ctx.zkey_new(tmp_path / "big.r1cs", tmp_path / "pot.ptau", tmp_path / "x.zkey")
+    from oracle.py import groth16 as g16
+    ptau = (tmp_path / "pot.ptau").read_bytes()
+    secs = [(t, ptau[pos:pos + ln]) for t, lst in g16.read_binfile(ptau, "ptau", 1).items() for pos, ln in lst if t < 12]
+    (tmp_path / "raw.ptau").write_bytes(g16.write_binfile("ptau", 1, secs))
+    with pytest.raises(zk.ZkpoaError, match="prepared for phase 2"):
+        ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "raw.ptau", tmp_path / "x.zkey")
+    rc = subprocess.run([zk.SETUP_BIN, "only-one-arg"], capture_output=True, text=True)
+    assert rc.returncode == 2 and "usage" in rc.stderr

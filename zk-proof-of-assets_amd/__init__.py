@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkpoa_prover.so")
 PROVER_BIN = os.path.join(_HERE, "prover")
 MERKLE_BIN = os.path.join(_HERE, "merkle-tree")
+SETUP_BIN = os.path.join(_HERE, "zkpoa-setup")
 
 PROVER_OK = 0
 PROVER_ERROR = 1
@@ -28,7 +29,7 @@ EXPORTS = [
     "groth16_prover", "groth16_prover_zkey_file",
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
-    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate",
+    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new",
     "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
@@ -127,6 +128,7 @@ def lib():
         L.zkpoa_setup_accumulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                              ctypes.c_uint64, ctypes.c_void_p]
+        L.zkpoa_zkey_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         L.zkpoa_zkey_load_device_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint,
                                                    ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int] + \
             [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
@@ -364,6 +366,11 @@ class Context:
         one zkey point section of `snarkjs zkey new` (include/zkpoa_prover.h: zkpoa_setup_accumulate)."""
         self._check(lib().zkpoa_setup_accumulate(self._h, group, d_points, n_points, d_coefs, d_point_index, d_signal,
                                                  nnz, n_signals, d_out), "zkpoa_setup_accumulate")
+
+    def zkey_new(self, r1cs_path, ptau_path, zkey_path):
+        """`snarkjs zkey new` on files (include/zkpoa_prover.h: zkpoa_zkey_new)."""
+        self._check(lib().zkpoa_zkey_new(self._h, os.fsencode(r1cs_path), os.fsencode(ptau_path),
+                                         os.fsencode(zkey_path)), "zkpoa_zkey_new")
 
     def load_zkey_device_shard(self, n_vars, n_public, log_domain, rank, world, split, d_A, d_B1, d_B2, d_C, d_H,
                                d_coefs, n_coefs, header_points):

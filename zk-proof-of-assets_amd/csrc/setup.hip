@@ -21,7 +21,23 @@
 #include "hooks.hip.h"
 #include "zkpoa_internal.hpp"
 
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
 using namespace zkpoa;
+
+namespace zkpoa {
+template <> Affine<HFq> host_generator<HFq>();     // hooks_g1.hip
+template <> Affine<HFq2> host_generator<HFq2>();   // hooks_g2.hip
+}
 
 namespace {
 
@@ -155,5 +171,312 @@ extern "C" int zkpoa_setup_accumulate(zkpoa_context* ctx, int group, const void*
     throw HipError("setup_accumulate: null pointer");
   if (group == 1) setup_accumulate<Fq>(ctx, d_points, n_points, d_coefs, d_point_index, d_signal, nnz, n_signals, d_out);
   else setup_accumulate<Fq2>(ctx, d_points, n_points, d_coefs, d_point_index, d_signal, nnz, n_signals, d_out);
+  ZK_API_END(ctx)
+}
+
+// ---- `snarkjs zkey new <circuit.r1cs> <pot.ptau> <circuit_0.zkey>` (g16_setup.sh:243-246) on files -----------------------
+namespace {
+
+struct SetupError : std::runtime_error {
+  explicit SetupError(const std::string& m) : std::runtime_error(m) {}
+};
+
+uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+struct MappedFile {
+  const uint8_t* p = nullptr;
+  uint64_t size = 0;
+  int fd = -1;
+  explicit MappedFile(const char* path) {
+    fd = open(path, O_RDONLY);
+    if (fd < 0) throw SetupError(std::string("cannot open ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) {
+      close(fd);
+      throw SetupError(std::string("cannot stat ") + path);
+    }
+    size = (uint64_t)sb.st_size;
+    void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) {
+      close(fd);
+      throw SetupError(std::string("cannot map ") + path);
+    }
+    p = static_cast<const uint8_t*>(m);
+  }
+  ~MappedFile() {
+    if (p) munmap(const_cast<uint8_t*>(p), size);
+    if (fd >= 0) close(fd);
+  }
+  MappedFile(const MappedFile&) = delete;
+  MappedFile& operator=(const MappedFile&) = delete;
+};
+
+struct Sec {
+  uint64_t off = 0, len = 0;
+  bool present = false;
+};
+
+// iden3 binary container: magic(4) version(u32) nSections(u32) then { type(u32) size(u64) payload }
+std::map<uint32_t, Sec> bin_sections(const MappedFile& f, const char* magic, uint32_t max_version, const char* what) {
+  if (f.size < 12 || memcmp(f.p, magic, 4) != 0) throw SetupError(std::string(what) + ": bad magic");
+  if (rd32(f.p + 4) > max_version) throw SetupError(std::string(what) + ": unsupported version");
+  const uint32_t n = rd32(f.p + 8);
+  std::map<uint32_t, Sec> out;
+  uint64_t pos = 12;
+  for (uint32_t i = 0; i < n; i++) {
+    if (pos + 12 > f.size) throw SetupError(std::string(what) + ": truncated section table");
+    const uint32_t type = rd32(f.p + pos);
+    const uint64_t len = rd64(f.p + pos + 4);
+    pos += 12;
+    if (len > f.size - pos) throw SetupError(std::string(what) + ": section runs past the end of the file");
+    if (!out.count(type)) out[type] = Sec{pos, len, true};   // the first section of a type (as snarkjs' readers)
+    pos += len;
+  }
+  return out;
+}
+
+struct Term {
+  uint32_t c, s;
+  uint8_t coef[32];
+};
+
+struct R1cs {
+  uint32_t nWires = 0, nPublic = 0, nConstraints = 0;
+  std::vector<Term> A, B, C;   // per constraint in file order, terms of one linear combination ascending by signal
+};
+
+R1cs parse_r1cs(const MappedFile& f) {
+  auto secs = bin_sections(f, "r1cs", 1, "r1cs");
+  if (!secs.count(1) || !secs.count(2)) throw SetupError("r1cs: header or constraint section missing");
+  const Sec h = secs[1], cs = secs[2];
+  if (h.len < 4 + 32 + 4 * 4 + 8 + 4 || rd32(f.p + h.off) != 32) throw SetupError("r1cs: header too short or field size != 32");
+  for (int i = 0; i < 4; i++)
+    if (rd64(f.p + h.off + 4 + 8 * i) != HFrParams::P[i]) throw SetupError("r1cs: not over the BN254 scalar field");
+  const uint8_t* q = f.p + h.off + 36;
+  R1cs r;
+  r.nWires = rd32(q);
+  r.nPublic = rd32(q + 4) + rd32(q + 8);   // outputs + public inputs
+  r.nConstraints = rd32(q + 24);
+  if (r.nWires == 0 || (uint64_t)r.nPublic + 1 > r.nWires) throw SetupError("r1cs: inconsistent wire counts");
+  uint64_t pos = cs.off;
+  const uint64_t end = cs.off + cs.len;
+  std::vector<Term> lc;
+  for (uint32_t c = 0; c < r.nConstraints; c++) {
+    for (int m = 0; m < 3; m++) {
+      if (pos + 4 > end) throw SetupError("r1cs: constraint section truncated");
+      const uint32_t nt = rd32(f.p + pos);
+      pos += 4;
+      if ((uint64_t)nt * 36 > end - pos) throw SetupError("r1cs: constraint section truncated");
+      lc.clear();
+      for (uint32_t t = 0; t < nt; t++, pos += 36) {
+        Term x;
+        x.c = c;
+        x.s = rd32(f.p + pos);
+        memcpy(x.coef, f.p + pos + 4, 32);
+        if (x.s >= r.nWires) throw SetupError("r1cs: wire index out of range");
+        uint64_t v[4];
+        memcpy(v, x.coef, 32);
+        if (HFr::geq_p(v)) throw SetupError("r1cs: coefficient is not a field element (>= r)");
+        lc.push_back(x);
+      }
+      // snarkjs holds a linear combination as an object keyed by the signal: iteration is ascending by signal
+      std::stable_sort(lc.begin(), lc.end(), [](const Term& a, const Term& b) { return a.s < b.s; });
+      for (size_t t = 1; t < lc.size(); t++)
+        if (lc[t].s == lc[t - 1].s) throw SetupError("r1cs: a signal occurs twice in one linear combination");
+      std::vector<Term>& dst = m == 0 ? r.A : (m == 1 ? r.B : r.C);
+      dst.insert(dst.end(), lc.begin(), lc.end());
+    }
+  }
+  return r;
+}
+
+void pread_all(int fd, void* dst, uint64_t len, uint64_t off, const char* what) {
+  uint64_t got = 0;
+  while (got < len) {
+    ssize_t n = pread(fd, static_cast<char*>(dst) + got, len - got, (off_t)(off + got));
+    if (n <= 0) throw SetupError(std::string("ptau: short read of ") + what);
+    got += (uint64_t)n;
+  }
+}
+
+struct DevArr {
+  void* p = nullptr;
+  explicit DevArr(size_t bytes) { ZK_HIP(hipMalloc(&p, bytes ? bytes : 1)); }
+  ~DevArr() { if (p) (void)hipFree(p); }
+  DevArr(const DevArr&) = delete;
+  DevArr& operator=(const DevArr&) = delete;
+  void up(const void* src, size_t bytes, size_t at = 0) {
+    if (bytes) ZK_HIP(hipMemcpy(static_cast<char*>(p) + at, src, bytes, hipMemcpyHostToDevice));
+  }
+};
+
+struct Entries {   // one zkpoa_setup_accumulate call
+  std::vector<uint8_t> coef;
+  std::vector<uint32_t> pidx, sig;
+  void add(const Term& t, uint32_t point_offset) {
+    coef.insert(coef.end(), t.coef, t.coef + 32);
+    pidx.push_back(point_offset + t.c);
+    sig.push_back(t.s);
+  }
+  void add_one(uint32_t point, uint32_t signal) {
+    uint8_t one[32] = {1};
+    coef.insert(coef.end(), one, one + 32);
+    pidx.push_back(point);
+    sig.push_back(signal);
+  }
+};
+
+template <class F>
+std::vector<uint8_t> run_accumulate(zkpoa_context* ctx, const DevArr& points, uint64_t n_points, const Entries& e,
+                                    uint64_t n_signals) {
+  constexpr size_t A = MsmSizes<F>::kAffine;
+  const uint64_t nnz = e.sig.size();
+  DevArr coef(nnz * 32), pidx(nnz * 4), sig(nnz * 4), out(n_signals * A);
+  coef.up(e.coef.data(), nnz * 32);
+  pidx.up(e.pidx.data(), nnz * 4);
+  sig.up(e.sig.data(), nnz * 4);
+  setup_accumulate<F>(ctx, points.p, n_points, coef.p, (const uint32_t*)pidx.p, (const uint32_t*)sig.p, nnz, n_signals, out.p);
+  std::vector<uint8_t> host(n_signals * A);
+  if (!host.empty()) ZK_HIP(hipMemcpy(host.data(), out.p, host.size(), hipMemcpyDeviceToHost));
+  return host;
+}
+
+void put32(std::vector<uint8_t>& v, uint32_t x) { v.insert(v.end(), (uint8_t*)&x, (uint8_t*)&x + 4); }
+void put64(std::vector<uint8_t>& v, uint64_t x) { v.insert(v.end(), (uint8_t*)&x, (uint8_t*)&x + 8); }
+
+void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path) {
+  MappedFile fr(r1cs_path);
+  const R1cs r = parse_r1cs(fr);
+  // domain: the smallest power of two that holds the constraints and the nPublic + 1 extra rows (zkey_new.js)
+  uint32_t cp = 0;
+  while ((1ull << cp) < (uint64_t)r.nConstraints + r.nPublic + 1) cp++;
+  if (cp > 27) throw SetupError("circuit too large (domain above 2^27)");
+  const uint64_t n = 1ull << cp;
+
+  MappedFile fp(ptau_path);   // mapped for the section table only; the point ranges are read with pread
+  auto ps = bin_sections(fp, "ptau", 1, "ptau");
+  for (uint32_t t : {1u, 4u, 5u, 6u, 12u, 13u, 14u, 15u})
+    if (!ps.count(t)) throw SetupError("ptau: section " + std::to_string(t) + " missing (the file must be prepared for phase 2)");
+  const Sec h = ps[1];
+  if (h.len < 4 + 32 + 8 || rd32(fp.p + h.off) != 32) throw SetupError("ptau: header too short or field size != 32");
+  for (int i = 0; i < 4; i++)
+    if (rd64(fp.p + h.off + 4 + 8 * i) != HFqParams::P[i]) throw SetupError("ptau: not a BN254 ceremony");
+  const uint32_t power = rd32(fp.p + h.off + 36);
+  if (cp > power) throw SetupError("ptau: ceremony of 2^" + std::to_string(power) + " is too small for a 2^" + std::to_string(cp) + " domain");
+  auto level = [&](uint32_t sec, uint32_t lvl, uint64_t unit, uint64_t count, const char* what) {
+    const uint64_t off = ((1ull << lvl) - 1) * unit;
+    if (off + count * unit > ps[sec].len) throw SetupError(std::string("ptau: section too short for ") + what);
+    return ps[sec].off + off;
+  };
+  std::vector<uint8_t> L1(n * 64), L2(n * 128), aL(n * 64), bL(n * 64), Hs(2 * n * 64);
+  pread_all(fp.fd, L1.data(), L1.size(), level(12, cp, 64, n, "tau*G1 (Lagrange)"), "tau*G1 (Lagrange)");
+  pread_all(fp.fd, L2.data(), L2.size(), level(13, cp, 128, n, "tau*G2 (Lagrange)"), "tau*G2 (Lagrange)");
+  pread_all(fp.fd, aL.data(), aL.size(), level(14, cp, 64, n, "alpha*tau*G1 (Lagrange)"), "alpha*tau*G1 (Lagrange)");
+  pread_all(fp.fd, bL.data(), bL.size(), level(15, cp, 64, n, "beta*tau*G1 (Lagrange)"), "beta*tau*G1 (Lagrange)");
+  pread_all(fp.fd, Hs.data(), Hs.size(), level(12, cp + 1, 64, 2 * n, "tau*G1 (Lagrange, 2n)"), "tau*G1 (Lagrange, 2n)");
+  uint8_t alpha1[64], beta1[64], beta2[128];
+  if (ps[4].len < 64 || ps[5].len < 64 || ps[6].len < 128) throw SetupError("ptau: alpha / beta sections too short");
+  pread_all(fp.fd, alpha1, 64, ps[4].off, "alpha*G1");
+  pread_all(fp.fd, beta1, 64, ps[5].off, "beta*G1");
+  pread_all(fp.fd, beta2, 128, ps[6].off, "beta*G2");
+
+  // entries of the three accumulations (+ the nPublic + 1 rows `1 * signal_i` that bind the public inputs)
+  Entries eA, eB, eK;
+  for (const Term& t : r.A) { eA.add(t, 0); eK.add(t, 0); }                      // K: A over beta*L  (points [0, n))
+  for (const Term& t : r.B) { eB.add(t, 0); eK.add(t, (uint32_t)n); }            //    B over alpha*L ([n, 2n))
+  for (const Term& t : r.C) eK.add(t, (uint32_t)(2 * n));                         //    C over L       ([2n, 3n))
+  for (uint32_t i = 0; i <= r.nPublic; i++) {
+    eA.add_one(r.nConstraints + i, i);
+    eK.add_one(r.nConstraints + i, i);
+  }
+  const uint64_t m = r.nWires;
+  std::vector<uint8_t> secA, secB1, secB2, secK;
+  {
+    DevArr dL1(n * 64);
+    dL1.up(L1.data(), L1.size());
+    secA = run_accumulate<Fq>(ctx, dL1, n, eA, m);
+    secB1 = run_accumulate<Fq>(ctx, dL1, n, eB, m);
+  }
+  {
+    DevArr dL2(n * 128);
+    dL2.up(L2.data(), L2.size());
+    secB2 = run_accumulate<Fq2>(ctx, dL2, n, eB, m);
+  }
+  {
+    DevArr dK(3 * n * 64);
+    dK.up(bL.data(), n * 64, 0);
+    dK.up(aL.data(), n * 64, n * 64);
+    dK.up(L1.data(), n * 64, 2 * n * 64);
+    secK = run_accumulate<Fq>(ctx, dK, 3 * n, eK, m);
+  }
+
+  // ---- the file: sections 1-10 in the order snarkjs numbers them
+  std::vector<uint8_t> s2, s4, s9(n * 64), s10(64 + 4, 0);
+  put32(s2, 32);
+  s2.insert(s2.end(), (const uint8_t*)HFqParams::P, (const uint8_t*)HFqParams::P + 32);
+  put32(s2, 32);
+  s2.insert(s2.end(), (const uint8_t*)HFrParams::P, (const uint8_t*)HFrParams::P + 32);
+  put32(s2, r.nWires);
+  put32(s2, r.nPublic);
+  put32(s2, (uint32_t)n);
+  uint8_t g1[64], g2[128];
+  h_affine_to_bytes<HFq>(host_generator<HFq>(), g1);
+  h_affine_to_bytes<HFq2>(host_generator<HFq2>(), g2);
+  s2.insert(s2.end(), alpha1, alpha1 + 64);
+  s2.insert(s2.end(), beta1, beta1 + 64);
+  s2.insert(s2.end(), beta2, beta2 + 128);
+  s2.insert(s2.end(), g2, g2 + 128);   // gamma2 = the generator until a contribution changes delta
+  s2.insert(s2.end(), g1, g1 + 64);    // delta1
+  s2.insert(s2.end(), g2, g2 + 128);   // delta2
+  // coefficients: A and B terms per constraint, then the public rows; values scaled by R^2
+  const uint64_t nCoefs = r.A.size() + r.B.size() + r.nPublic + 1;
+  if (nCoefs > 0xffffffffull) throw SetupError("more than 2^32 coefficients");
+  put32(s4, (uint32_t)nCoefs);
+  s4.reserve(4 + nCoefs * 44);
+  auto rec = [&](uint32_t mtx, uint32_t c, uint32_t sgn, const uint8_t* coef) {
+    put32(s4, mtx);
+    put32(s4, c);
+    put32(s4, sgn);
+    HFr v = HFr::from_bytes(coef).to_mont();   // limbs = coef * R
+    HFr w = v.to_mont();                       // limbs = coef * R^2
+    s4.insert(s4.end(), (const uint8_t*)w.l, (const uint8_t*)w.l + 32);
+  };
+  {
+    size_t ia = 0, ib = 0;
+    for (uint32_t c = 0; c < r.nConstraints; c++) {
+      for (; ia < r.A.size() && r.A[ia].c == c; ia++) rec(0, c, r.A[ia].s, r.A[ia].coef);
+      for (; ib < r.B.size() && r.B[ib].c == c; ib++) rec(1, c, r.B[ib].s, r.B[ib].coef);
+    }
+    const uint8_t one[32] = {1};
+    for (uint32_t i = 0; i <= r.nPublic; i++) rec(0, r.nConstraints + i, i, one);
+  }
+  for (uint64_t i = 0; i < n; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
+  const size_t icb = ((size_t)r.nPublic + 1) * 64;
+  struct Out { uint32_t id; const uint8_t* p; uint64_t len; };
+  const uint32_t one_u32 = 1;   // section 1: protocol id 1 = groth16
+  const Out outs[] = {{1, (const uint8_t*)&one_u32, 4}, {2, s2.data(), s2.size()}, {3, secK.data(), icb},
+                      {4, s4.data(), s4.size()}, {5, secA.data(), secA.size()}, {6, secB1.data(), secB1.size()},
+                      {7, secB2.data(), secB2.size()}, {8, secK.data() + icb, secK.size() - icb},
+                      {9, s9.data(), s9.size()}, {10, s10.data(), s10.size()}};
+  FILE* fo = fopen(zkey_path, "wb");
+  if (!fo) throw SetupError(std::string("cannot create ") + zkey_path);
+  bool ok = fwrite("zkey", 1, 4, fo) == 4;
+  const uint32_t hdr[2] = {1, 10};
+  ok = ok && fwrite(hdr, 4, 2, fo) == 2;
+  for (const Out& o : outs) {
+    ok = ok && fwrite(&o.id, 4, 1, fo) == 1 && fwrite(&o.len, 8, 1, fo) == 1;
+    ok = ok && (o.len == 0 || fwrite(o.p, 1, o.len, fo) == o.len);
+  }
+  ok = (fclose(fo) == 0) && ok;
+  if (!ok) throw SetupError(std::string("write to ") + zkey_path + " failed");
+}
+
+}  // namespace
+
+extern "C" int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path) {
+  ZK_API_BEGIN(ctx)
+  if (!r1cs_path || !ptau_path || !zkey_path) throw SetupError("zkey new: null path");
+  zkey_new(ctx, r1cs_path, ptau_path, zkey_path);
   ZK_API_END(ctx)
 }
