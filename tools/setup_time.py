@@ -1,0 +1,60 @@
+"""Timing of the phase-2 setup arithmetic (zkpoa_setup_accumulate) at the reference's layer-one shape: 2^21
+constraints, 2.08 M signals, 6.3 M coefficients (3 per constraint, as the synthetic prove workload has), with an R1CS-like
+coefficient mix (1, -1, small constants, a few powers of two and full-width values) and a hot signal (the constant one).
+Points are (a + i b) G from the device generator -- for timing only (parity: tests/test_gpu_setup.py)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from __graft_entry__ import load_package
+z = load_package()
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 21
+n = 1 << k
+m = {21: 2083343, 25: 21400000}.get(k, n - 1000)
+ctx = z.Context(0)
+rng = np.random.default_rng(3)
+nnz_a, nnz_b = 2 * n, n
+def coefs(cnt):
+    u = rng.random(cnt)
+    out = np.zeros((cnt, 4), dtype=np.uint64)
+    out[:, 0] = 1
+    neg = (u >= 0.45) & (u < 0.70)                      # r - 1
+    rl = [(R - 1 >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    out[neg] = np.array(rl, dtype=np.uint64)
+    small = (u >= 0.70) & (u < 0.90)
+    out[small, 0] = rng.integers(2, 1 << 16, size=int(small.sum()), dtype=np.uint64)
+    p2 = (u >= 0.90) & (u < 0.97)                       # 2^j, j < 252
+    j = rng.integers(0, 252, size=int(p2.sum()))
+    t = np.zeros((int(p2.sum()), 4), dtype=np.uint64)
+    t[np.arange(len(j)), j // 64] = np.uint64(1) << (j % 64).astype(np.uint64)
+    out[p2] = t
+    full = u >= 0.97
+    f = rng.integers(0, 1 << 63, size=(int(full.sum()), 4), dtype=np.uint64)
+    f[:, 3] &= np.uint64((1 << 60) - 1)
+    out[full] = f
+    return torch.from_numpy(out.view(np.uint8).reshape(-1)).cuda()
+def sigs(cnt, hot):
+    s = rng.integers(0, m, size=cnt, dtype=np.int64)
+    s[rng.random(cnt) < hot] = 0
+    return torch.from_numpy(s.astype(np.int32)).cuda()
+def pidx(cnt, npts):
+    return torch.from_numpy(rng.integers(0, npts, size=cnt, dtype=np.int64).astype(np.int32)).cuda()
+g1 = torch.empty(3 * n * 64, dtype=torch.uint8, device="cuda")
+g2 = torch.empty(n * 128, dtype=torch.uint8, device="cuda")
+ctx.gen_bases_g1_device(12345, 67890, 0, 3 * n, g1.data_ptr())
+ctx.gen_bases_g2_device(12345, 67890, 0, n, g2.data_ptr())
+cases = [("A  (section 5, G1)", 1, g1, n, nnz_a, 0.02), ("B1 (section 6, G1)", 1, g1, n, nnz_b, 0.02),
+         ("B2 (section 7, G2)", 2, g2, n, nnz_b, 0.02), ("IC + C (sections 3 + 8, G1 over 3n points)", 1, g1, 3 * n, 2 * nnz_a + nnz_b, 0.05)]
+total = 0.0
+for name, grp, pts, npts, nnz, hot in cases:
+    c, s, p = coefs(nnz), sigs(nnz, hot), pidx(nnz, npts)
+    out = torch.empty(m * (64 if grp == 1 else 128), dtype=torch.uint8, device="cuda")
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx.setup_accumulate(grp, pts.data_ptr(), npts, c.data_ptr(), p.data_ptr(), s.data_ptr(), nnz, m, out.data_ptr())
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    total += best
+    print("%-46s %9d entries -> %8d signals: %8.1f ms" % (name, nnz, m, best * 1e3))
+print("domain 2^%d: point sections of `snarkjs zkey new` in %.2f s on the device" % (k, total))
