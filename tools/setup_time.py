@@ -58,3 +58,51 @@ for name, grp, pts, npts, nnz, hot in cases:
     total += best
     print("%-46s %9d entries -> %8d signals: %8.1f ms" % (name, nnz, m, best * 1e3))
 print("domain 2^%d: point sections of `snarkjs zkey new` in %.2f s on the device" % (k, total))
+
+# ---- the whole command on files: zkpoa-setup <r1cs> <ptau> <zkey> at the same shape (format-valid inputs: the "ceremony"
+# points come from the device generator, the constraints are the synthetic prove workload's: 2 A terms, 1 B term, 1 C term)
+if "--files" in sys.argv:
+    import struct, subprocess, tempfile
+    d = tempfile.mkdtemp()
+    n_cons = n - 2
+    npub = 1
+    t0 = time.perf_counter()
+    le32 = lambda x: int(x).to_bytes(32, "little")
+    # r1cs: constraint c = (w[a] + k w[b]) * w[d] = w[e]
+    a = rng.integers(1, m, size=n_cons, dtype=np.uint32); b = rng.integers(1, m, size=n_cons, dtype=np.uint32)
+    b[a == b] = 0
+    dd = rng.integers(0, m, size=n_cons, dtype=np.uint32); e = rng.integers(0, m, size=n_cons, dtype=np.uint32)
+    rec = np.zeros((n_cons, 4 + 36 + 36 + 4 + 36 + 4 + 36), dtype=np.uint8)
+    def put_u32(col, arr): rec[:, col:col + 4] = arr.astype("<u4").view(np.uint8).reshape(-1, 4)
+    put_u32(0, np.full(n_cons, 2, dtype=np.uint32)); put_u32(4, a); rec[:, 8] = 1
+    put_u32(40, b); rec[:, 44:76] = coefs(n_cons).cpu().numpy().reshape(n_cons, 32)
+    put_u32(76, np.full(n_cons, 1, dtype=np.uint32)); put_u32(80, dd); rec[:, 84] = 1
+    put_u32(116, np.full(n_cons, 1, dtype=np.uint32)); put_u32(120, e); rec[:, 124] = 1
+    hdr = struct.pack("<I", 32) + le32(R) + struct.pack("<IIIIQI", m, 0, npub, m - npub - 1, m, n_cons)
+    body = rec.tobytes()
+    with open(d + "/c.r1cs", "wb") as f:
+        f.write(b"r1cs" + struct.pack("<II", 1, 2))
+        f.write(struct.pack("<IQ", 1, len(hdr)) + hdr)
+        f.write(struct.pack("<IQ", 2, len(body))); f.write(body)
+    # ptau of power k: only what the setup reads carries data (sections 4-6 heads, 12-15); 2, 3, 7 are present but empty
+    Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    def g1pts(cnt, seed):
+        t = torch.empty(cnt * 64, dtype=torch.uint8, device="cuda"); ctx.gen_bases_g1_device(seed, seed + 7, 0, cnt, t.data_ptr()); return t.cpu().numpy().tobytes()
+    def g2pts(cnt, seed):
+        t = torch.empty(cnt * 128, dtype=torch.uint8, device="cuda"); ctx.gen_bases_g2_device(seed, seed + 7, 0, cnt, t.data_ptr()); return t.cpu().numpy().tobytes()
+    secs = [(1, struct.pack("<I", 32) + le32(Q) + struct.pack("<II", k, k)), (2, b""), (3, b""), (4, g1pts(1, 11)),
+            (5, g1pts(1, 12)), (6, g2pts(1, 13)), (7, struct.pack("<I", 0)), (12, g1pts((4 << k) - 1, 14)),
+            (13, g2pts((2 << k) - 1, 15)), (14, g1pts((2 << k) - 1, 16)), (15, g1pts((2 << k) - 1, 17))]
+    with open(d + "/pot.ptau", "wb") as f:
+        f.write(b"ptau" + struct.pack("<II", 1, len(secs)))
+        for sid, payload in secs:
+            f.write(struct.pack("<IQ", sid, len(payload))); f.write(payload)
+    print("inputs written in %.1f s: r1cs %.2f GB, ptau %.2f GB" % (time.perf_counter() - t0, os.path.getsize(d + "/c.r1cs") / 1e9, os.path.getsize(d + "/pot.ptau") / 1e9))
+    for i in range(2):
+        t0 = time.perf_counter()
+        rc = subprocess.run([z.SETUP_BIN, "zkey", "new", d + "/c.r1cs", d + "/pot.ptau", d + "/c_0.zkey"], capture_output=True, text=True, env=dict(os.environ, ZKPOA_VERBOSE="1"))
+        print("zkpoa-setup zkey new, run %d: %.2f s wall, rc=%d, zkey %.2f GB  %s" % (i, time.perf_counter() - t0, rc.returncode, os.path.getsize(d + "/c_0.zkey") / 1e9 if rc.returncode == 0 else 0, rc.stderr.strip().splitlines()[-1] if rc.stderr.strip() else ""))
+    # the key it wrote must load (section sizes, coordinate and coefficient range checks of the prover's loader)
+    key = ctx.load_zkey(open(d + "/c_0.zkey", "rb").read()); key.close()
+    print("the prover loads the key")
+    import shutil; shutil.rmtree(d)
