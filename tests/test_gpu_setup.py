@@ -174,3 +174,36 @@ def test_zkpoa_setup_cli_and_rejections(ctx, zk, tmp_path):
         ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "raw.ptau", tmp_path / "x.zkey")
     rc = subprocess.run([zk.SETUP_BIN, "only-one-arg"], capture_output=True, text=True)
     assert rc.returncode == 2 and "usage" in rc.stderr
+
+
+def test_zkey_new_survives_mutated_inputs(ctx, zk, tmp_path):
+    """Bytes of the two input files flipped, cut or overwritten with extreme counts: every call either writes a key
+    or fails with a ZkpoaError -- no crash, no hang -- and the context stays usable."""
+    from setup_files import write_ptau
+    rng = random.Random(99)
+    cons, w, tox, want, vk, r1cs, power = _setup_case(rng, 25, 2, 30)
+    ptau = write_ptau(power, tox["tau"], tox["alpha"], tox["beta"])
+    (tmp_path / "ok.r1cs").write_bytes(r1cs)
+    (tmp_path / "ok.ptau").write_bytes(ptau)
+    extremes = [b"\xff\xff\xff\xff", b"\0\0\0\0", b"\xff\xff\xff\x7f", b"\x01\0\0\x80"]
+    outcomes = {"ok": 0, "rejected": 0}
+    for it in range(80):
+        which = it % 2
+        b = bytearray(r1cs if which == 0 else ptau)
+        for _ in range(rng.choice([1, 1, 2, 3])):
+            op, i = rng.randrange(4), rng.randrange(min(len(b), 400 if rng.random() < 0.7 else len(b)))
+            if op == 0: b[i] = rng.randrange(256)
+            elif op == 1: b[i:i + 4] = rng.choice(extremes)
+            elif op == 2: b = b[:max(1, rng.randrange(len(b)))]
+            else: b[i:i + 8] = rng.randrange(1 << 64).to_bytes(8, "little")
+        name = "m.r1cs" if which == 0 else "m.ptau"
+        (tmp_path / name).write_bytes(bytes(b))
+        try:
+            ctx.zkey_new(tmp_path / ("m.r1cs" if which == 0 else "ok.r1cs"),
+                         tmp_path / ("m.ptau" if which == 1 else "ok.ptau"), tmp_path / "m.zkey")
+            outcomes["ok"] += 1
+        except zk.ZkpoaError:
+            outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 10
+    ctx.zkey_new(tmp_path / "ok.r1cs", tmp_path / "ok.ptau", tmp_path / "final.zkey")
+    assert (tmp_path / "final.zkey").read_bytes() == want
