@@ -255,6 +255,13 @@ int zkpoa_setup_accumulate(zkpoa_context* ctx, int group, const void* d_points, 
  * is not restated (nothing in the reference pins it), so the key proves and verifies but `snarkjs zkey verify` would
  * not accept its hash. The `zkpoa-setup` executable takes snarkjs' argument order. Errors: zkpoa_last_error. */
 int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path);
+/* The arithmetic of `snarkjs zkey contribute <in.zkey> <out.zkey>` (g16_setup.sh:262-266): with a secret d (delta_le:
+ * 32 B little-endian in [1, r); NULL = drawn from /dev/urandom), delta1, delta2 <- d * delta1, d * delta2 and every
+ * point of sections 8 (C) and 9 (H) <- (1/d) * point (device; one scalar for all points, so no lane diverges). All
+ * other sections are copied. NOT produced: the contribution record of section 10 (public key of d, proof of
+ * knowledge, transcript hash) -- snarkjs' transcript is not restated, so the result proves and verifies under its new
+ * verification key but carries no publicly checkable trail; use snarkjs where that trail is the point. */
+int zkpoa_zkey_contribute(zkpoa_context* ctx, const char* zkey_in_path, const char* zkey_out_path, const uint8_t* delta_le);
 
 /* ---- the step after the path; host only, no GPU ----------------------------------------
  * zkpoa_groth16_verify: `npx snarkjs groth16 verify <vkey> <public> <proof>` (scripts/g16_verify.sh:213-216)

@@ -3,6 +3,7 @@ out[s] = sum over the entries of signal s of coef * point. The points are k_i * 
 fixed-base products), so the expected output is (sum coef * k_i mod r) * G from the oracle -- bit-exact, G1 and G2,
 with the coefficient shapes an R1CS has (1, -1 = r - 1, small constants, powers of two, full-width), a hot signal
 (the constant-one wire), empty signals, single-entry signals, and the documented rejections."""
+import os
 import random
 
 import numpy as np
@@ -207,3 +208,65 @@ def test_zkey_new_survives_mutated_inputs(ctx, zk, tmp_path):
     assert outcomes["rejected"] > 10
     ctx.zkey_new(tmp_path / "ok.r1cs", tmp_path / "ok.ptau", tmp_path / "final.zkey")
     assert (tmp_path / "final.zkey").read_bytes() == want
+
+
+# ---- the arithmetic of `snarkjs zkey contribute`: delta <- d * delta, C and H <- C / d, H / d -----------------------
+def _zkey_sections(buf):
+    from oracle.py import groth16 as g16
+    return {t: buf[lst[0][0]:lst[0][0] + lst[0][1]] for t, lst in g16.read_binfile(buf, "zkey", 1).items()}
+
+
+def test_zkey_contribute_equals_the_setup_with_that_delta(ctx, zk, tmp_path):
+    """new -> contribute(d1) -> contribute(d2): every section equals the oracle's key for delta = d1, then d1 * d2
+    (gamma = 1), byte for byte; the contributed key proves (self-check on) and verifies, and the proof made under the
+    old key does not verify under the new one."""
+    import subprocess
+    from oracle.py import groth16 as g16
+    from setup_files import write_ptau
+    rng = random.Random(404)
+    n_vars, n_public, n_cons = 60, 2, 90
+    cons, w, tox, want0, vk, r1cs, power = _setup_case(rng, n_vars, n_public, n_cons)
+    (tmp_path / "c.r1cs").write_bytes(r1cs)
+    (tmp_path / "pot.ptau").write_bytes(write_ptau(power, tox["tau"], tox["alpha"], tox["beta"]))
+    ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "pot.ptau", tmp_path / "c_0.zkey")
+    d1, d2 = rng.randrange(1, R), R - 5
+    fb1 = lambda s: co.fixed_base_g1(b"".join(le(k) for k in s), 8)
+    fb2 = lambda s: co.fixed_base_g2(b"".join(le(k) for k in s), 8)
+    ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "c_1.zkey", d1)
+    want1, _ = g16.synthetic_setup(n_vars, n_public, cons, dict(tox, delta=d1), g1_batch=fb1, g2_batch=fb2)
+    assert (tmp_path / "c_1.zkey").read_bytes() == want1
+    # second contribution through the executable, snarkjs' command line (options ignored), secret from ZKPOA_DELTA
+    rc = subprocess.run([zk.SETUP_BIN, "zkey", "contribute", "c_1.zkey", "c_final.zkey", "--name=First contributor",
+                         "-e=random text for entropy"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, ZKPOA_DELTA=str(d2)))
+    assert rc.returncode == 0 and "WARNING" in rc.stderr, rc.stderr
+    want2, _ = g16.synthetic_setup(n_vars, n_public, cons, dict(tox, delta=d1 * d2 % R), g1_batch=fb1, g2_batch=fb2)
+    final = (tmp_path / "c_final.zkey").read_bytes()
+    assert final == want2
+    wt = g16.write_wtns(w)
+    k0, k2 = ctx.load_zkey(want0), ctx.load_zkey(final)
+    try:
+        pts0, pub0 = ctx.prove(k0, wt, 3, 4)
+        pts2, pub2 = ctx.prove(k2, wt, 3, 4)                         # self-check against the new delta
+        assert pub0 == pub2 and pts0 != pts2
+        assert zk.groth16_verify_points(k2.vkey_points(), pts2, pub2)
+        assert not zk.groth16_verify_points(k2.vkey_points(), pts0, pub0)
+    finally:
+        k0.close(); k2.close()
+    # a random secret (no ZKPOA_DELTA): a different, working key
+    rc = subprocess.run([zk.SETUP_BIN, "zkey", "contribute", "c_0.zkey", "c_r.zkey"], cwd=tmp_path, capture_output=True,
+                        text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "ZKPOA_DELTA"})
+    assert rc.returncode == 0, rc.stderr
+    rnd = (tmp_path / "c_r.zkey").read_bytes()
+    s0, sr = _zkey_sections(want0), _zkey_sections(rnd)
+    assert all(sr[t] == s0[t] for t in (1, 3, 4, 5, 6, 7, 10)) and sr[8] != s0[8] and sr[9] != s0[9] and sr[2] != s0[2]
+    kr = ctx.load_zkey(rnd)
+    try:
+        ptsr, pubr = ctx.prove(kr, wt, 1, 2)
+        assert zk.groth16_verify_points(kr.vkey_points(), ptsr, pubr)
+    finally:
+        kr.close()
+    with pytest.raises(zk.ZkpoaError, match="delta"):
+        ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "x.zkey", 0)
+    with pytest.raises(zk.ZkpoaError, match="delta"):
+        ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "x.zkey", R)

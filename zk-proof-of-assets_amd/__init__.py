@@ -29,7 +29,7 @@ EXPORTS = [
     "groth16_prover", "groth16_prover_zkey_file",
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
-    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new",
+    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute",
     "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
@@ -129,6 +129,7 @@ def lib():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                              ctypes.c_uint64, ctypes.c_void_p]
         L.zkpoa_zkey_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.zkpoa_zkey_contribute.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         L.zkpoa_zkey_load_device_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint,
                                                    ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int] + \
             [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
@@ -371,6 +372,12 @@ class Context:
         """`snarkjs zkey new` on files (include/zkpoa_prover.h: zkpoa_zkey_new)."""
         self._check(lib().zkpoa_zkey_new(self._h, os.fsencode(r1cs_path), os.fsencode(ptau_path),
                                          os.fsencode(zkey_path)), "zkpoa_zkey_new")
+
+    def zkey_contribute(self, zkey_in_path, zkey_out_path, delta=None):
+        """The arithmetic of `snarkjs zkey contribute` (delta: int in [1, r), None = random)."""
+        d = None if delta is None else int(delta).to_bytes(32, "little")
+        self._check(lib().zkpoa_zkey_contribute(self._h, os.fsencode(zkey_in_path), os.fsencode(zkey_out_path), d),
+                    "zkpoa_zkey_contribute")
 
     def load_zkey_device_shard(self, n_vars, n_public, log_domain, rank, world, split, d_A, d_B1, d_B2, d_C, d_H,
                                d_coefs, n_coefs, header_points):

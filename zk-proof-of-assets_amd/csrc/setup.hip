@@ -102,6 +102,71 @@ static __global__ __launch_bounds__(256) void setup_mul_kernel(const void* __res
   else store_xyzz(items, j, acc);
 }
 
+// out[i] = k * in[i] for one scalar k (sign-normalised by the caller: `neg` adds -P), XYZZ into scratch
+struct ScalarArg {
+  uint32_t l[8];
+};
+template <class F>
+static __global__ __launch_bounds__(256) void setup_scale_kernel(const void* __restrict__ in, uint64_t i0, uint32_t cnt,
+                                                                 ScalarArg k, int top, bool neg,
+                                                                 void* __restrict__ out_xyzz) {
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= cnt) return;
+  const Affine<F> p = load_affine<F>(in, i0 + t);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (int bit = top; bit >= 0; bit--) {   // the scalar is the same in every lane: no divergence
+    acc = xyzz_dbl(acc);
+    if ((k.l[bit >> 5] >> (bit & 31)) & 1u) xyzz_add_affine(acc, p, neg);
+  }
+  store_xyzz(out_xyzz, t, acc);
+}
+
+// d_out[i] = k * d_in[i], i < n, wire format in and out (k: 32 B little-endian standard form, < r)
+template <class F>
+void setup_scale(zkpoa_context* ctx, const void* d_in, uint64_t n, const uint8_t k_le[32], void* d_out) {
+  if (n == 0) return;
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  HFr kh = HFr::from_bytes(k_le);
+  uint64_t half[4] = {0, 0, 0, 0};   // (r - 1) / 2
+  {
+    uint64_t c = 0;
+    for (int i = 3; i >= 0; i--) {
+      half[i] = (HFrParams::P[i] >> 1) | (c << 63);
+      c = HFrParams::P[i] & 1;
+    }
+  }
+  bool neg = false;
+  for (int i = 3; i >= 0; i--) {
+    if (kh.l[i] > half[i]) { neg = true; break; }
+    if (kh.l[i] < half[i]) break;
+  }
+  if (neg) {   // k > r / 2: (r - k) * (-P)
+    HFr r_minus = HFr{{HFrParams::P[0], HFrParams::P[1], HFrParams::P[2], HFrParams::P[3]}};
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 d = (unsigned __int128)r_minus.l[i] - kh.l[i] - bw;
+      kh.l[i] = (uint64_t)d;
+      bw = (d >> 64) & 1;
+    }
+  }
+  ScalarArg ka;
+  memcpy(ka.l, kh.l, 32);
+  int top = -1;
+  for (int i = 7; i >= 0 && top < 0; i--)
+    if (ka.l[i]) top = 32 * i + (31 - __builtin_clz(ka.l[i]));
+  const uint64_t slab = 1ull << 22;
+  DevBuf scratch((size_t)(n < slab ? n : slab) * MsmSizes<F>::kXyzz);
+  for (uint64_t off = 0; off < n; off += slab) {
+    const uint32_t cnt = (uint32_t)(n - off < slab ? n - off : slab);
+    hipLaunchKernelGGL((setup_scale_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, st, d_in, off, cnt, ka, top, neg,
+                       scratch.p);
+    hipLaunchKernelGGL((xyzz_to_affine_kernel<F>), dim3((cnt + 255) / 256), dim3(256), 0, st, (const void*)scratch.p,
+                       (void*)(reinterpret_cast<char*>(d_out) + off * MsmSizes<F>::kAffine), (uint64_t)cnt);
+  }
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+}
+
 template <class F>
 void setup_accumulate(zkpoa_context* ctx, const void* d_points, uint64_t n_points, const void* d_coefs,
                       const uint32_t* d_pidx, const uint32_t* d_sig, uint64_t nnz, uint64_t n_signals, void* d_out) {
@@ -472,7 +537,90 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   if (!ok) throw SetupError(std::string("write to ") + zkey_path + " failed");
 }
 
+// ---- the arithmetic of `snarkjs zkey contribute` (g16_setup.sh:262-266): delta <- d * delta, C and H <- C, H / d ---------
+void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_path, const uint8_t* delta_le) {
+  MappedFile fi(in_path);
+  auto secs = bin_sections(fi, "zkey", 1, "zkey");
+  for (uint32_t t = 1; t <= 10; t++)
+    if (!secs.count(t)) throw SetupError("zkey: section " + std::to_string(t) + " missing");
+  const Sec h = secs[2];
+  const uint64_t kHdr = 4 + 32 + 4 + 32 + 12, kDelta1 = kHdr + 64 + 64 + 128 + 128, kDelta2 = kDelta1 + 64;
+  if (h.len != kDelta2 + 128 || rd32(fi.p + h.off) != 32 || rd32(fi.p + h.off + 36) != 32)
+    throw SetupError("zkey: groth16 header has the wrong size");
+  for (int i = 0; i < 4; i++)
+    if (rd64(fi.p + h.off + 4 + 8 * i) != HFqParams::P[i] || rd64(fi.p + h.off + 40 + 8 * i) != HFrParams::P[i])
+      throw SetupError("zkey: not a BN254 key");
+  const uint64_t nVars = rd32(fi.p + h.off + 72), nPublic = rd32(fi.p + h.off + 76), domain = rd32(fi.p + h.off + 80);
+  if (nPublic + 1 > nVars || secs[8].len != (nVars - nPublic - 1) * 64 || secs[9].len != domain * 64)
+    throw SetupError("zkey: C or H section has the wrong size");
+  uint8_t d[32];
+  if (delta_le) memcpy(d, delta_le, 32);
+  else {   // uniform on [1, r): 254 random bits, rejected while >= r or zero
+    int fd = open("/dev/urandom", O_RDONLY);
+    if (fd < 0) throw SetupError("cannot open /dev/urandom");
+    for (;;) {
+      if (read(fd, d, 32) != 32) {
+        close(fd);
+        throw SetupError("short read from /dev/urandom");
+      }
+      d[31] &= 0x3f;
+      uint64_t v[4];
+      memcpy(v, d, 32);
+      if (!HFr::geq_p(v) && (v[0] | v[1] | v[2] | v[3])) break;
+    }
+    close(fd);
+  }
+  uint64_t dv[4];
+  memcpy(dv, d, 32);
+  if (HFr::geq_p(dv) || !(dv[0] | dv[1] | dv[2] | dv[3])) throw SetupError("contribute: delta must be in [1, r)");
+  HFr dinv = HFr::from_bytes(d).to_mont().inv().from_mont();
+  uint8_t dinv_le[32];
+  memcpy(dinv_le, dinv.l, 32);
+
+  std::vector<uint8_t> s2(fi.p + h.off, fi.p + h.off + h.len);
+  {
+    Affine<HFq> d1 = h_affine_from_bytes<HFq>(&s2[kDelta1]);
+    Affine<HFq2> d2 = h_affine_from_bytes<HFq2>(&s2[kDelta2]);
+    h_affine_to_bytes<HFq>(h_to_affine(h_mul(XYZZ<HFq>::from_affine(d1), dv)), &s2[kDelta1]);
+    h_affine_to_bytes<HFq2>(h_to_affine(h_mul(XYZZ<HFq2>::from_affine(d2), dv)), &s2[kDelta2]);
+  }
+  auto scaled = [&](const Sec& sc) {
+    std::vector<uint8_t> out(sc.len);
+    if (sc.len) {
+      DevArr in(sc.len), res(sc.len);
+      in.up(fi.p + sc.off, sc.len);
+      setup_scale<Fq>(ctx, in.p, sc.len / 64, dinv_le, res.p);
+      ZK_HIP(hipMemcpy(out.data(), res.p, sc.len, hipMemcpyDeviceToHost));
+    }
+    return out;
+  };
+  const std::vector<uint8_t> s8 = scaled(secs[8]), s9 = scaled(secs[9]);
+  FILE* fo = fopen(out_path, "wb");
+  if (!fo) throw SetupError(std::string("cannot create ") + out_path);
+  bool ok = fwrite("zkey", 1, 4, fo) == 4;
+  const uint32_t hdr[2] = {1, 10};
+  ok = ok && fwrite(hdr, 4, 2, fo) == 2;
+  for (uint32_t t = 1; t <= 10; t++) {
+    const uint8_t* p = fi.p + secs[t].off;
+    uint64_t len = secs[t].len;
+    if (t == 2) p = s2.data();
+    if (t == 8) p = s8.data();
+    if (t == 9) p = s9.data();
+    ok = ok && fwrite(&t, 4, 1, fo) == 1 && fwrite(&len, 8, 1, fo) == 1 && (len == 0 || fwrite(p, 1, len, fo) == len);
+  }
+  ok = (fclose(fo) == 0) && ok;
+  if (!ok) throw SetupError(std::string("write to ") + out_path + " failed");
+}
+
 }  // namespace
+
+extern "C" int zkpoa_zkey_contribute(zkpoa_context* ctx, const char* zkey_in_path, const char* zkey_out_path,
+                                     const uint8_t* delta_le) {
+  ZK_API_BEGIN(ctx)
+  if (!zkey_in_path || !zkey_out_path) throw SetupError("zkey contribute: null path");
+  zkey_contribute(ctx, zkey_in_path, zkey_out_path, delta_le);
+  ZK_API_END(ctx)
+}
 
 extern "C" int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path) {
   ZK_API_BEGIN(ctx)
