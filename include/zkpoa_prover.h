@@ -262,6 +262,11 @@ int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_p
  * knowledge, transcript hash) -- snarkjs' transcript is not restated, so the result proves and verifies under its new
  * verification key but carries no publicly checkable trail; use snarkjs where that trail is the point. */
 int zkpoa_zkey_contribute(zkpoa_context* ctx, const char* zkey_in_path, const char* zkey_out_path, const uint8_t* delta_le);
+/* `snarkjs wtns check <circuit.r1cs> <witness.wtns>` (scripts/g16_verify.sh:205-210): every constraint's
+ * <A, w> * <B, w> == <C, w> on the device. *violated <- how many constraints fail (0 = "WITNESS IS CORRECT"),
+ * *first_violated (optional) <- the smallest failing constraint index. PROVER_ERROR for malformed files. */
+int zkpoa_wtns_check(zkpoa_context* ctx, const char* r1cs_path, const char* wtns_path, uint64_t* violated,
+                     uint64_t* first_violated);
 
 /* ---- the step after the path; host only, no GPU ----------------------------------------
  * zkpoa_groth16_verify: `npx snarkjs groth16 verify <vkey> <public> <proof>` (scripts/g16_verify.sh:213-216)

@@ -270,3 +270,38 @@ def test_zkey_contribute_equals_the_setup_with_that_delta(ctx, zk, tmp_path):
         ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "x.zkey", 0)
     with pytest.raises(zk.ZkpoaError, match="delta"):
         ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "x.zkey", R)
+
+
+# ---- `snarkjs wtns check` -------------------------------------------------------------------------------------------
+def test_wtns_check(ctx, zk, tmp_path):
+    import subprocess
+    from oracle.py import groth16 as g16
+    from setup_files import write_r1cs
+    rng = random.Random(8)
+    n_vars, n_public, n_cons = 200, 3, 700
+    cons, w = g16.random_circuit(rng, n_vars, n_public, n_cons)
+    (tmp_path / "c.r1cs").write_bytes(write_r1cs(n_vars, n_public, cons))
+    (tmp_path / "w.wtns").write_bytes(g16.write_wtns(w))
+    assert ctx.wtns_check(tmp_path / "c.r1cs", tmp_path / "w.wtns") == (0, None)
+    rc = subprocess.run([zk.SETUP_BIN, "wtns", "check", "c.r1cs", "w.wtns"], cwd=tmp_path, capture_output=True, text=True)
+    assert rc.returncode == 0 and "WITNESS IS CORRECT" in rc.stdout, rc.stderr
+    # break one wire: exactly the constraints that mention it (with a non-zero effect) fail; the oracle counts them
+    bad_w = list(w)
+    victim = n_vars - 5
+    bad_w[victim] = (bad_w[victim] + 1) % R
+    lc = lambda d, ww: sum(v * ww[s] for s, v in d.items()) % R
+    failing = [c for c, (a, b, cc) in enumerate(cons) if lc(a, bad_w) * lc(b, bad_w) % R != lc(cc, bad_w)]
+    assert failing
+    (tmp_path / "bad.wtns").write_bytes(g16.write_wtns(bad_w))
+    assert ctx.wtns_check(tmp_path / "c.r1cs", tmp_path / "bad.wtns") == (len(failing), failing[0])
+    rc = subprocess.run([zk.SETUP_BIN, "wtns", "check", "c.r1cs", "bad.wtns"], cwd=tmp_path, capture_output=True, text=True)
+    assert rc.returncode == 1 and ("#%d" % failing[0]) in rc.stderr
+    # malformed: wrong number of values; a value >= r
+    (tmp_path / "short.wtns").write_bytes(g16.write_wtns(w[:-1]))
+    with pytest.raises(zk.ZkpoaError, match="wires"):
+        ctx.wtns_check(tmp_path / "c.r1cs", tmp_path / "short.wtns")
+    raw = bytearray(g16.write_wtns(w))
+    raw[-32:] = le(R)
+    (tmp_path / "big.wtns").write_bytes(bytes(raw))
+    with pytest.raises(zk.ZkpoaError, match="field element"):
+        ctx.wtns_check(tmp_path / "c.r1cs", tmp_path / "big.wtns")

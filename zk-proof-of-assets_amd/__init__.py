@@ -29,7 +29,7 @@ EXPORTS = [
     "groth16_prover", "groth16_prover_zkey_file",
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
-    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute",
+    "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute", "zkpoa_wtns_check",
     "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
@@ -129,6 +129,8 @@ def lib():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                              ctypes.c_uint64, ctypes.c_void_p]
         L.zkpoa_zkey_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+        L.zkpoa_wtns_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p,
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.zkpoa_zkey_contribute.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
         L.zkpoa_zkey_load_device_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint,
                                                    ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int] + \
@@ -372,6 +374,13 @@ class Context:
         """`snarkjs zkey new` on files (include/zkpoa_prover.h: zkpoa_zkey_new)."""
         self._check(lib().zkpoa_zkey_new(self._h, os.fsencode(r1cs_path), os.fsencode(ptau_path),
                                          os.fsencode(zkey_path)), "zkpoa_zkey_new")
+
+    def wtns_check(self, r1cs_path, wtns_path):
+        """`snarkjs wtns check`: -> (number of violated constraints, smallest violated index or None)."""
+        bad, first = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(lib().zkpoa_wtns_check(self._h, os.fsencode(r1cs_path), os.fsencode(wtns_path), ctypes.byref(bad),
+                                           ctypes.byref(first)), "zkpoa_wtns_check")
+        return int(bad.value), (int(first.value) if bad.value else None)
 
     def zkey_contribute(self, zkey_in_path, zkey_out_path, delta=None):
         """The arithmetic of `snarkjs zkey contribute` (delta: int in [1, r), None = random)."""

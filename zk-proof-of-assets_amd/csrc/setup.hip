@@ -102,6 +102,43 @@ static __global__ __launch_bounds__(256) void setup_mul_kernel(const void* __res
   else store_xyzz(items, j, acc);
 }
 
+// ---- `snarkjs wtns check`: constraint c holds iff <A_c, w> * <B_c, w> == <C_c, w> ------------------------------------
+// row_ptr[3 * c + m .. +1): the terms of matrix m of constraint c; coefficients and witness in Montgomery form.
+// flags[0] = number of violated constraints, flags[1] = the smallest violated index (atomicMin, starts at ~0).
+static __global__ __launch_bounds__(256) void wtns_check_kernel(const uint32_t* __restrict__ row_ptr,
+                                                                const uint32_t* __restrict__ sig,
+                                                                const void* __restrict__ coef_m,
+                                                                const void* __restrict__ w_m, uint32_t n_cons,
+                                                                uint32_t* __restrict__ flags) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= n_cons) return;
+  Fr v[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    Fr acc = Fr::zero();
+    for (uint32_t t = row_ptr[3 * c + m]; t < row_ptr[3 * c + m + 1]; t++)
+      acc = acc + load_field<Fr>(reinterpret_cast<const char*>(coef_m) + 32 * (size_t)t) *
+                      load_field<Fr>(reinterpret_cast<const char*>(w_m) + 32 * (size_t)sig[t]);
+    v[m] = acc;
+  }
+  if (!(v[0] * v[1] - v[2]).is_zero()) {
+    atomicAdd(&flags[0], 1u);
+    atomicMin(&flags[1], c);
+  }
+}
+// in place: standard form (canonical, < r checked by the caller's flag) -> Montgomery
+static __global__ __launch_bounds__(256) void fr_to_mont_kernel(void* __restrict__ data, uint64_t n, uint32_t* __restrict__ bad) {
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  char* p = reinterpret_cast<char*>(data) + 32 * i;
+  Fr v = load_field<Fr>(p);
+  uint32_t bw = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) (void)subb(v.l[k], FrParams::P[k], bw);
+  if (!bw) atomicOr(bad, 1u);
+  store_field(p, v.to_mont());
+}
+
 // out[i] = k * in[i] for one scalar k (sign-normalised by the caller: `neg` adds -P), XYZZ into scratch
 struct ScalarArg {
   uint32_t l[8];
@@ -537,6 +574,67 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   if (!ok) throw SetupError(std::string("write to ") + zkey_path + " failed");
 }
 
+// ---- `snarkjs wtns check <circuit.r1cs> <witness.wtns>` (g16_verify.sh:205-210) ---------------------------------------------
+// returns the number of violated constraints; *first_bad = the smallest violated constraint index
+uint64_t wtns_check(zkpoa_context* ctx, const char* r1cs_path, const char* wtns_path, uint64_t* first_bad) {
+  MappedFile fr(r1cs_path);
+  const R1cs r = parse_r1cs(fr);
+  MappedFile fw(wtns_path);
+  auto ws = bin_sections(fw, "wtns", 2, "wtns");
+  if (!ws.count(1) || !ws.count(2)) throw SetupError("wtns: header or data section missing");
+  const Sec wh = ws[1], wd = ws[2];
+  if (wh.len != 4 + 32 + 4 || rd32(fw.p + wh.off) != 32) throw SetupError("wtns: header has the wrong size");
+  for (int i = 0; i < 4; i++)
+    if (rd64(fw.p + wh.off + 4 + 8 * i) != HFrParams::P[i]) throw SetupError("wtns: not over the BN254 scalar field");
+  const uint64_t nw = rd32(fw.p + wh.off + 36);
+  if (nw != r.nWires) throw SetupError("wtns: " + std::to_string(nw) + " values for a circuit of " + std::to_string(r.nWires) + " wires");
+  if (wd.len != nw * 32) throw SetupError("wtns: data section has the wrong size");
+  // CSR over (constraint, matrix): the three term lists are already grouped by constraint in file order
+  const uint64_t nnz = r.A.size() + r.B.size() + r.C.size();
+  if (nnz >= (1ull << 32)) throw SetupError("more than 2^32 coefficients");
+  std::vector<uint32_t> row_ptr(3 * (size_t)r.nConstraints + 1, 0), sig(nnz);
+  std::vector<uint8_t> coef(nnz * 32);
+  {
+    size_t ia = 0, ib = 0, ic = 0, t = 0;
+    auto take = [&](const std::vector<Term>& v, size_t& i, uint32_t c) {
+      for (; i < v.size() && v[i].c == c; i++, t++) {
+        sig[t] = v[i].s;
+        memcpy(&coef[t * 32], v[i].coef, 32);
+      }
+    };
+    for (uint32_t c = 0; c < r.nConstraints; c++) {
+      row_ptr[3 * (size_t)c] = (uint32_t)t;
+      take(r.A, ia, c);
+      row_ptr[3 * (size_t)c + 1] = (uint32_t)t;
+      take(r.B, ib, c);
+      row_ptr[3 * (size_t)c + 2] = (uint32_t)t;
+      take(r.C, ic, c);
+    }
+    row_ptr[3 * (size_t)r.nConstraints] = (uint32_t)t;
+  }
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  DevArr d_rp(row_ptr.size() * 4), d_sig(nnz * 4), d_coef(nnz * 32), d_w(nw * 32), d_flags(64);
+  d_rp.up(row_ptr.data(), row_ptr.size() * 4);
+  d_sig.up(sig.data(), nnz * 4);
+  d_coef.up(coef.data(), nnz * 32);
+  d_w.up(fw.p + wd.off, nw * 32);
+  const uint32_t init[4] = {0, 0xffffffffu, 0, 0};
+  d_flags.up(init, 16);
+  uint32_t* fl = reinterpret_cast<uint32_t*>(d_flags.p);
+  if (nnz) hipLaunchKernelGGL(fr_to_mont_kernel, dim3((uint32_t)((nnz + 255) / 256)), dim3(256), 0, st, d_coef.p, nnz, fl + 2);
+  hipLaunchKernelGGL(fr_to_mont_kernel, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, d_w.p, nw, fl + 3);
+  if (r.nConstraints)
+    hipLaunchKernelGGL(wtns_check_kernel, dim3((r.nConstraints + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_rp.p,
+                       (const uint32_t*)d_sig.p, (const void*)d_coef.p, (const void*)d_w.p, r.nConstraints, fl);
+  msm_read_back(ctx->dev.lanes[0], fl, 16);
+  ZK_HIP(hipGetLastError());
+  const uint32_t* hb = reinterpret_cast<const uint32_t*>(ctx->dev.lanes[0].pinned);
+  if (hb[3]) throw SetupError("wtns: a value is not a field element (>= r)");
+  if (hb[2]) throw SetupError("r1cs: a coefficient is not a field element (>= r)");
+  if (first_bad) *first_bad = hb[1];
+  return hb[0];
+}
+
 // ---- the arithmetic of `snarkjs zkey contribute` (g16_setup.sh:262-266): delta <- d * delta, C and H <- C, H / d ---------
 void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_path, const uint8_t* delta_le) {
   MappedFile fi(in_path);
@@ -613,6 +711,14 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
 }
 
 }  // namespace
+
+extern "C" int zkpoa_wtns_check(zkpoa_context* ctx, const char* r1cs_path, const char* wtns_path, uint64_t* violated,
+                                uint64_t* first_violated) {
+  ZK_API_BEGIN(ctx)
+  if (!r1cs_path || !wtns_path || !violated) throw SetupError("wtns check: null argument");
+  *violated = wtns_check(ctx, r1cs_path, wtns_path, first_violated);
+  ZK_API_END(ctx)
+}
 
 extern "C" int zkpoa_zkey_contribute(zkpoa_context* ctx, const char* zkey_in_path, const char* zkey_out_path,
                                      const uint8_t* delta_le) {

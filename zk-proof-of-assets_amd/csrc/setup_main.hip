@@ -2,6 +2,7 @@
 //     snarkjs zkey new      <circuit.r1cs> <pot.ptau> <circuit_0.zkey>
 //     snarkjs groth16 setup <circuit.r1cs> <pot.ptau> <circuit_0.zkey>
 //     snarkjs zkey contribute <circuit_0.zkey> <circuit_final.zkey> --name="..." -e="..."     (:262-266; arithmetic only)
+//     snarkjs wtns check <circuit.r1cs> <witness.wtns>                                      (scripts/g16_verify.sh:205-210)
 // Same three file arguments (the words `zkey new` / `groth16 setup` are accepted and ignored, so the command line
 // can be kept as it is with the executable swapped). The .ptau must be prepared for phase 2 (`snarkjs powersoftau
 // prepare phase2`), as snarkjs requires too. Exit status 0 / non-zero + message on stderr.
@@ -35,9 +36,12 @@ static bool parse_decimal_or_hex(const char* s, uint8_t out[32]) {   // ZKPOA_DE
 
 int main(int argc, char** argv) {
   int a = 1;
-  bool contribute = false;
+  bool contribute = false, check = false;
   if (argc - a >= 2 && !strcmp(argv[a], "zkey") && !strcmp(argv[a + 1], "contribute")) {
     contribute = true;
+    a += 2;
+  } else if (argc - a >= 2 && !strcmp(argv[a], "wtns") && !strcmp(argv[a + 1], "check")) {
+    check = true;
     a += 2;
   } else if (argc - a >= 2 && ((!strcmp(argv[a], "zkey") && !strcmp(argv[a + 1], "new")) ||
                                (!strcmp(argv[a], "groth16") && !strcmp(argv[a + 1], "setup")))) {
@@ -52,9 +56,10 @@ int main(int argc, char** argv) {
     if (npos < 3) pos[npos] = argv[i];
     npos++;
   }
-  if (npos != (contribute ? 2 : 3)) {
+  if (npos != (contribute || check ? 2 : 3)) {
     fprintf(stderr, "usage: zkpoa-setup [zkey new | groth16 setup] <circuit.r1cs> <pot.ptau> <circuit_0.zkey>\n"
-                    "       zkpoa-setup zkey contribute <in.zkey> <out.zkey> [--name=...] [-e=...]\n");
+                    "       zkpoa-setup zkey contribute <in.zkey> <out.zkey> [--name=...] [-e=...]\n"
+                    "       zkpoa-setup wtns check <circuit.r1cs> <witness.wtns>\n");
     return 2;
   }
   uint8_t delta[32];
@@ -75,11 +80,24 @@ int main(int argc, char** argv) {
     fprintf(stderr, "zkpoa-setup: %s\n", err);
     return 1;
   }
-  int rc = contribute ? zkpoa_zkey_contribute(ctx, pos[0], pos[1], delta_p) : zkpoa_zkey_new(ctx, pos[0], pos[1], pos[2]);
+  int rc;
+  if (check) {   // snarkjs prints "WITNESS IS CORRECT" and exits 0, or names the failure and exits 1
+    uint64_t bad = 0, first = 0;
+    rc = zkpoa_wtns_check(ctx, pos[0], pos[1], &bad, &first);
+    if (rc == PROVER_OK && bad == 0) printf("[INFO]  zkpoa: WITNESS IS CORRECT\n");
+    if (rc == PROVER_OK && bad) {
+      fprintf(stderr, "[ERROR] zkpoa: WITNESS CHECK FAILED: %llu constraint(s) do not hold, the first is #%llu\n",
+              (unsigned long long)bad, (unsigned long long)first);
+      zkpoa_context_destroy(ctx);
+      return 1;
+    }
+  } else {
+    rc = contribute ? zkpoa_zkey_contribute(ctx, pos[0], pos[1], delta_p) : zkpoa_zkey_new(ctx, pos[0], pos[1], pos[2]);
+  }
   if (rc != PROVER_OK) fprintf(stderr, "zkpoa-setup: %s\n", zkpoa_last_error(ctx));
   zkpoa_context_destroy(ctx);
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  if (rc == PROVER_OK && getenv("ZKPOA_VERBOSE"))
+  if (rc == PROVER_OK && getenv("ZKPOA_VERBOSE") && !check)
     fprintf(stderr, "zkpoa-setup: %s written in %.2f s\n", pos[contribute ? 1 : 2],
             (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) / 1e9);
   return rc == PROVER_OK ? 0 : 1;
