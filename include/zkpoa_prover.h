@@ -61,7 +61,10 @@ int groth16_prover_zkey_file(const char* zkey_file_path,
 typedef struct zkpoa_context zkpoa_context;
 typedef struct zkpoa_zkey zkpoa_zkey;
 
-/* Creates a context on HIP device `device` (streams + workspace). Fails if no GPU. */
+/* Creates a context on HIP device `device` (streams + workspace). Fails if no GPU.
+ * Threads: a context is not re-entrant -- calls on one context must not overlap, with one exception: the lane-addressed
+ * MSM calls (zkpoa_msm_g1_device_lane, zkpoa_msm_table_run_lane) may run concurrently on DISTINCT lanes. Use one
+ * context per host thread (or per GPU) otherwise; the one-shot groth16_prover* entry points serialise themselves. */
 int zkpoa_context_create(int device, zkpoa_context** ctx, char* error_msg, unsigned long error_msg_maxsize);
 void zkpoa_context_destroy(zkpoa_context* ctx);
 /* message of the last failing call on this context (valid until the next call) */
