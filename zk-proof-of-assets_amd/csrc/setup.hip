@@ -12,8 +12,9 @@
 //
 // Device mapping (one call per section; zkpoa_setup_accumulate):
 //   1. histogram of the entries by signal (atomics), exclusive scan -> segment offsets, scatter of the entry ids;
-//   2. one lane per entry, in segment order: k * P by MSB-first double-and-add on the sign-normalised coefficient
-//      (k > r/2 -> (r - k) * (-P): "-1" is one addition, not 254 doublings), XYZZ result into the segment's slot;
+//   2. one lane per entry: k * P by MSB-first double-and-add on the sign-normalised coefficient (k > r/2 ->
+//      (r - k) * (-P): "-1" is one addition, not 254 doublings), XYZZ result into the entry's slot in segment order;
+//      lanes take the entries sorted by coefficient length, so a wave's lanes run equally long;
 //   3. the MSM's partial-sum levels (msm_accumN_kernel, fan-in 4: a hot segment is a chain of full additions, so
 //      depth matters) until every segment is one point; 4. XYZZ -> affine, zkey wire format.
 // The order inside a segment depends on the atomics; the sum does not, and the affine output is canonical.
@@ -73,17 +74,54 @@ static __global__ __launch_bounds__(256) void setup_scatter_kernel(const uint32_
   order[off[s] + atomicAdd(&cursor[s], 1u)] = e;
 }
 
-// slot j (segment order): Q = coef * P; a segment of one entry goes straight to its bucket
+// bit length (0..254) of the sign-normalised coefficient of entry e: the length of its double-and-add
+ZK_DEV uint32_t setup_bitlen(const void* __restrict__ coefs, uint32_t e) {
+  uint32_t k[8];
+  load_scalar(coefs, e, k);
+  (void)scalar_normalize(k);
+  uint32_t len = 0;
+#pragma unroll
+  for (int i = 7; i >= 0; i--)
+    if (len == 0 && k[i]) len = 32u * i + (32u - __builtin_clz(k[i]));
+  return len;
+}
+// counting sort of the slots by that length, longest first (256 keys): a wave runs as long as its longest
+// coefficient, and an R1CS mixes 1 and -1 (one addition) with full-width constants (254 doublings)
+static __global__ __launch_bounds__(256) void setup_len_hist_kernel(const void* __restrict__ coefs,
+                                                                    const uint32_t* __restrict__ order, uint32_t nnz,
+                                                                    uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j < nnz) atomicAdd(&h[255u - setup_bitlen(coefs, order[j])], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+static __global__ __launch_bounds__(256) void setup_len_scatter_kernel(const void* __restrict__ coefs,
+                                                                       const uint32_t* __restrict__ order, uint32_t nnz,
+                                                                       const uint32_t* __restrict__ start,
+                                                                       uint32_t* __restrict__ cursor,
+                                                                       uint32_t* __restrict__ by_len) {
+  uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= nnz) return;
+  uint32_t key = 255u - setup_bitlen(coefs, order[j]);
+  by_len[start[key] + atomicAdd(&cursor[key], 1u)] = j;
+}
+
+// thread t takes slot j = by_len[t] (segment order): Q = coef * P; a segment of one entry goes straight to its bucket
 template <class F>
 static __global__ __launch_bounds__(256) void setup_mul_kernel(const void* __restrict__ points,
                                                                const void* __restrict__ coefs,
                                                                const uint32_t* __restrict__ pidx,
                                                                const uint32_t* __restrict__ sig,
                                                                const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ by_len,
                                                                const uint32_t* __restrict__ off, uint32_t nnz,
                                                                void* __restrict__ buckets, void* __restrict__ items) {
-  uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  if (j >= nnz) return;
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nnz) return;
+  const uint32_t j = by_len[t];
   const uint32_t e = order[j], s = sig[e];
   uint32_t k[8];
   load_scalar(coefs, e, k);
@@ -216,7 +254,7 @@ void setup_accumulate(zkpoa_context* ctx, const void* d_points, uint64_t n_point
   constexpr size_t X = MsmSizes<F>::kXyzz;
   DevBuf counts((size_t)S * 4), off(((size_t)S + 1) * 4), po_b(((size_t)S + 1) * 4), po_c(((size_t)S + 1) * 4),
       block_sums(((size_t)S / kScanTile + 2) * 4), misc(64), order((size_t)(N ? N : 1) * 4), buckets((size_t)S * X),
-      items((size_t)(N ? N : 1) * X), items2(((size_t)N / 2 + 2) * X);
+      items((size_t)(N ? N : 1) * X), items2(((size_t)N / 2 + 2) * X), by_len((size_t)(N ? N : 1) * 4), len_hist(1024 * 4);
   uint32_t* m = reinterpret_cast<uint32_t*>(misc.p);   // [0] flags, [1] total, [2] max segment, [3] level total
   ZK_HIP(hipMemsetAsync(counts.p, 0, (size_t)S * 4, st));
   ZK_HIP(hipMemsetAsync(misc.p, 0, 64, st));
@@ -236,8 +274,15 @@ void setup_accumulate(zkpoa_context* ctx, const void* d_points, uint64_t n_point
     ZK_HIP(hipMemsetAsync(counts.p, 0, (size_t)S * 4, st));   // reused as the scatter cursors
     hipLaunchKernelGGL(setup_scatter_kernel, dim3(grid), dim3(256), 0, st, d_sig, N, (const uint32_t*)off.p,
                        (uint32_t*)counts.p, (uint32_t*)order.p);
+    // slots ordered by the length of their double-and-add (256 keys: histogram, 256-entry scan on one wave, scatter)
+    uint32_t* lh = reinterpret_cast<uint32_t*>(len_hist.p);   // [0, 256) counts, [256, 513) starts, [520, 776) cursors
+    ZK_HIP(hipMemsetAsync(len_hist.p, 0, 1024 * 4, st));
+    hipLaunchKernelGGL(setup_len_hist_kernel, dim3(grid), dim3(256), 0, st, d_coefs, (const uint32_t*)order.p, N, lh);
+    scan_u32(st, lh, 256, 0, 0, lh + 256, (uint32_t*)block_sums.p, m + 3, nullptr);
+    hipLaunchKernelGGL(setup_len_scatter_kernel, dim3(grid), dim3(256), 0, st, d_coefs, (const uint32_t*)order.p, N,
+                       (const uint32_t*)(lh + 256), lh + 520, (uint32_t*)by_len.p);
     hipLaunchKernelGGL((setup_mul_kernel<F>), dim3(grid), dim3(256), 0, st, d_points, d_coefs, d_pidx, d_sig,
-                       (const uint32_t*)order.p, (const uint32_t*)off.p, N, buckets.p, items.p);
+                       (const uint32_t*)order.p, (const uint32_t*)by_len.p, (const uint32_t*)off.p, N, buckets.p, items.p);
   }
   // partial-sum levels, as after the MSM's level 0 (msm_accum_phase): fan-in 4 until every segment is one point
   const uint32_t K = 4;
