@@ -509,7 +509,9 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
   const uint32_t per = len >> logParts;   // logParts <= min(logS, logRows)
   const uint32_t per_max = S >> logParts; // uniform trip count (S >= rows)
   XYZZ<F> acc = XYZZ<F>::inf();
-  // iterations [0, per_max): this thread's buckets from HBM; then logParts tree levels through LDS
+  // iterations [0, per_max): this thread's buckets from HBM; then logParts tree levels through LDS.
+  // (Tried and dropped, r02: handing each tree level's additions to the first threads of the workgroup so that idle
+  // lanes form whole waves that skip the addition -- fewer wave-additions, same depth: no gain alone or six in flight.)
   for (uint32_t it = 0; it < per_max + logParts; it++) {
     XYZZ<F> other = XYZZ<F>::inf();
     if (it < per_max) {
@@ -528,10 +530,8 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
 
 // Y[(g * nbits + b) * S_out + blockIdx.x] = sum of the X[g * E + idx], idx in this block's 256, whose weight has bit b
 // (g = w * 2 + grp; weight = idx for row sums, idx + 1 for column sums, 0 for padding entries).
-// ONE wave per workgroup: each lane adds its 4 entries, then 6 LDS tree levels. (A 256-thread workgroup would park
-// three of its four waves at the barriers for the whole tree -- and a parked wave holds its ~140 VGPRs, i.e. one of the
-// three slots per SIMD the accumulation kernels of the other MSMs in flight live on: with 288 such workgroups per
-// 2^20 MSM that cost 11 % of the six-in-flight rate.)
+// ONE wave per workgroup: each lane adds its 4 entries, then 6 LDS tree levels (a 256-thread workgroup would keep
+// three of its four waves parked at the barriers of the tree, each holding ~140 VGPRs).
 template <class F>
 static __global__ __launch_bounds__(64) void msm_bit_tree_sum_kernel(const void* __restrict__ X, uint32_t E,
                                                                      uint32_t logS, uint32_t logRows, uint32_t nbits,
