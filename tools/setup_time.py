@@ -102,6 +102,8 @@ if "--files" in sys.argv:
         t0 = time.perf_counter()
         rc = subprocess.run([z.SETUP_BIN, "zkey", "new", d + "/c.r1cs", d + "/pot.ptau", d + "/c_0.zkey"], capture_output=True, text=True, env=dict(os.environ, ZKPOA_VERBOSE="1"))
         print("zkpoa-setup zkey new, run %d: %.2f s wall, rc=%d, zkey %.2f GB  %s" % (i, time.perf_counter() - t0, rc.returncode, os.path.getsize(d + "/c_0.zkey") / 1e9 if rc.returncode == 0 else 0, rc.stderr.strip().splitlines()[-1] if rc.stderr.strip() else ""))
+        if i == 1:
+            print("\n".join("    " + l for l in rc.stderr.splitlines() if "zkey new:" in l))
     t0 = time.perf_counter()
     rc = subprocess.run([z.SETUP_BIN, "zkey", "contribute", d + "/c_0.zkey", d + "/c_final.zkey", "--name=First contributor", "-e=random text for entropy"], capture_output=True, text=True, env=dict(os.environ, ZKPOA_VERBOSE="1"))
     print("zkpoa-setup zkey contribute: %.2f s wall, rc=%d  %s" % (time.perf_counter() - t0, rc.returncode, rc.stderr.strip().splitlines()[-1] if rc.stderr.strip() else ""))

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -504,8 +505,19 @@ void put32(std::vector<uint8_t>& v, uint32_t x) { v.insert(v.end(), (uint8_t*)&x
 void put64(std::vector<uint8_t>& v, uint64_t x) { v.insert(v.end(), (uint8_t*)&x, (uint8_t*)&x + 8); }
 
 void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path) {
+  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  struct timespec tp0;
+  clock_gettime(CLOCK_MONOTONIC, &tp0);
+  auto phase = [&](const char* what) {   // ZKPOA_VERBOSE: where the command spends its time
+    if (!verbose) return;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "zkpoa: zkey new: %-38s %8.1f ms\n", what, (t.tv_sec - tp0.tv_sec) * 1e3 + (t.tv_nsec - tp0.tv_nsec) / 1e6);
+    tp0 = t;
+  };
   MappedFile fr(r1cs_path);
   const R1cs r = parse_r1cs(fr);
+  phase("r1cs parsed");
   // domain: the smallest power of two that holds the constraints and the nPublic + 1 extra rows (zkey_new.js)
   uint32_t cp = 0;
   while ((1ull << cp) < (uint64_t)r.nConstraints + r.nPublic + 1) cp++;
@@ -538,6 +550,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   pread_all(fp.fd, alpha1, 64, ps[4].off, "alpha*G1");
   pread_all(fp.fd, beta1, 64, ps[5].off, "beta*G1");
   pread_all(fp.fd, beta2, 128, ps[6].off, "beta*G2");
+  phase("ptau ranges read");
 
   // entries of the three accumulations (+ the nPublic + 1 rows `1 * signal_i` that bind the public inputs)
   Entries eA, eB, eK;
@@ -548,6 +561,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     eA.add_one(r.nConstraints + i, i);
     eK.add_one(r.nConstraints + i, i);
   }
+  phase("entry lists built");
   const uint64_t m = r.nWires;
   std::vector<uint8_t> secA, secB1, secB2, secK;
   {
@@ -569,6 +583,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     secK = run_accumulate<Fq>(ctx, dK, 3 * n, eK, m);
   }
 
+  phase("point sections (upload, device, download)");
   // ---- the file: sections 1-10 in the order snarkjs numbers them
   std::vector<uint8_t> s2, s4, s9(n * 64), s10(64 + 4, 0);
   put32(s2, 32);
@@ -609,6 +624,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     const uint8_t one[32] = {1};
     for (uint32_t i = 0; i <= r.nPublic; i++) rec(0, r.nConstraints + i, i, one);
   }
+  phase("coefficient section");
   for (uint64_t i = 0; i < n; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
   const size_t icb = ((size_t)r.nPublic + 1) * 64;
   struct Out { uint32_t id; const uint8_t* p; uint64_t len; };
@@ -628,6 +644,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   }
   ok = (fclose(fo) == 0) && ok;
   if (!ok) throw SetupError(std::string("write to ") + zkey_path + " failed");
+  phase("zkey written");
 }
 
 // ---- `snarkjs wtns check <circuit.r1cs> <witness.wtns>` (g16_verify.sh:205-210) ---------------------------------------------
