@@ -41,7 +41,7 @@ def pmc_traffic(workload, kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated on this access pattern:
     profiles/rNN_pmc_hbm_traffic.json, newest round first). None when this workload has not been profiled."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % rnd)
         try:
             with open(path) as f:
@@ -77,6 +77,11 @@ def host_cores():
     if os.environ.get("ZKPOA_BENCH_THREADS"):
         n = int(os.environ["ZKPOA_BENCH_THREADS"])
     return n
+
+
+def box_cores():
+    """Logical CPUs of the GPU box itself (the job's share of them is host_cores())."""
+    return os.cpu_count() or 1
 
 
 def classic_window(n):
@@ -289,16 +294,97 @@ def cpu_msm_baseline(env, d_bases, limbs, logn):
     chk = env.ctx.msm_g1_device(d_bases.data_ptr(), d_s.data_ptr(), ns)
     if chk != ref:
         raise BenchError("GPU and CPU-oracle MSM disagree on the baseline sample")
-    return {"value": ns / tcpu, "unit": "pts/s", "cores": cores, "nproc": cores, "kind": "port",
+    return {"value": ns / tcpu, "unit": "pts/s", "cores": cores, "nproc": box_cores(), "kind": "port",
             "sample": "first 2^%d points of the same workload, mean of %d MSMs; C oracle (oracle/c: plain-C "
                       "Pippenger, unsigned windows, Jacobian, u128 Montgomery, gcc -O3 -march=x86-64-v3 -madx), "
-                      "%d threads = every host core of the GPU box; a stand-in for rapidsnark (absent here), "
-                      "not a tuned CPU prover" % (sample_log, reps, cores),
+                      "%d threads = every core of this job's share of the GPU box (the box has nproc = %d logical CPUs); "
+                      "a stand-in for rapidsnark (absent here), not a tuned CPU prover" % (sample_log, reps, cores, box_cores()),
             "seconds": tcpu * reps}
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def prove_leg(env, k, steps, warmup, precompute=True):
+def gather_h_scalars(env, circ, split):
+    """The complete H-scalar vector (numpy uint64 [n, 4]) of the last proof, on rank 0 (None elsewhere when N > 1).
+    N = 1: read back from HBM. N > 1: every rank contributes what ITS H MSM consumed -- with the split chain its cyclic
+    shard (odd-coset indices i = rank mod N, in order of i div N), with the replicated chain its index range -- and
+    rank 0 puts the vector together."""
+    import numpy as np
+    import torch
+    from zkpoa_amd.sharding import shard_range
+    n, world, rank = circ.n, env.world, env.rank
+    if world == 1:
+        return circ.h_scalars()
+    rows = -(-n // world)
+    mine = np.zeros((rows, 4), dtype=np.uint64)
+    if split:
+        mine[:n // world] = circ.ctx.read_h_scalars(circ.key, n // world)
+    else:
+        lo, hi = shard_range(n, rank, world)
+        mine[:hi - lo] = circ.ctx.read_h_scalars(circ.key, n)[lo:hi]
+    t = torch.from_numpy(mine.view(np.uint8).reshape(-1)).to(env.args.cdev)
+    if t.is_cuda:
+        out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+        env.dist.all_gather_into_tensor(out, t)
+        parts = out.cpu().numpy().view(np.uint64).reshape(world, rows, 4) if rank == 0 else None
+    else:
+        outs = [torch.empty_like(t) for _ in range(world)]
+        env.dist.all_gather(outs, t)
+        parts = np.stack([o.numpy().view(np.uint64).reshape(rows, 4) for o in outs]) if rank == 0 else None
+    if rank != 0:
+        return None
+    P = np.empty((n, 4), dtype=np.uint64)
+    for g in range(world):
+        if split:
+            P[g::world] = parts[g][:n // world]
+        else:
+            lo, hi = shard_range(n, g, world)
+            P[lo:hi] = parts[g][:hi - lo]
+    return P
+
+
+def binfile(magic, version, sections):
+    """iden3 binfile container from (id, bytes-like) pairs, as one bytes object."""
+    out = [magic, int(version).to_bytes(4, "little"), len(sections).to_bytes(4, "little")]
+    for sid, payload in sections:
+        out += [int(sid).to_bytes(4, "little"), len(payload).to_bytes(8, "little"), payload]
+    return b"".join(out)
+
+
+def cpu_prove_baseline(env, circ, gpu_points):
+    """The same proof on the host: the synthetic key's sections are copied out of HBM into a .zkey image and the C
+    oracle (oracle/c: orc_prove -- buildABC, 6 NTTs, joinABC, the five Pippenger MSMs, assembly) proves it on the
+    job's cores with r = s = 0. Its 256 proof bytes must equal the GPU's: a whole-proof oracle parity at this shape."""
+    from oracle import c_oracle as co
+    cores = host_cores()
+    m, npub = circ.m, circ.n_public
+    hp = circ.header_points                            # alpha1 beta1 beta2 delta1 delta2
+    g2gen = hp[128:256]                                # gamma2: any G2 point (the prover never reads it)
+    sec2 = (b"".join([(32).to_bytes(4, "little"), Q_MOD.to_bytes(32, "little"), (32).to_bytes(4, "little"),
+                      R_MOD.to_bytes(32, "little"), m.to_bytes(4, "little"), npub.to_bytes(4, "little"),
+                      circ.n.to_bytes(4, "little")]) + hp[0:64] + hp[64:128] + hp[128:256] + g2gen + hp[256:320] + hp[320:448])
+    dev_bytes = lambda t, count, size: t[:count * size].cpu().numpy().tobytes()
+    zkey = binfile(b"zkey", 1, [
+        (1, (1).to_bytes(4, "little")), (2, sec2), (3, bytes(64 * (npub + 1))), (4, circ.coeff_section_bytes()),
+        (5, dev_bytes(circ.d_A, m, 64)), (6, dev_bytes(circ.d_B1, m, 64)), (7, dev_bytes(circ.d_B2, m, 128)),
+        (8, dev_bytes(circ.d_C, m - npub - 1, 64)), (9, dev_bytes(circ.d_H, circ.n, 64))])
+    wtns = binfile(b"wtns", 2, [(1, (32).to_bytes(4, "little") + R_MOD.to_bytes(32, "little") + m.to_bytes(4, "little")),
+                                (2, circ.witness_bytes())])
+    tc = time.perf_counter()
+    ref, _ = co.prove(zkey, wtns, 0, 0, cores, n_public=npub)
+    tcpu = time.perf_counter() - tc
+    if ref != gpu_points:
+        raise BenchError("GPU proof and C-oracle proof differ (r = s = 0)")
+    return {"value": 1.0 / tcpu, "unit": "proofs/s", "cores": cores, "nproc": box_cores(), "kind": "port",
+            "sample": "ONE complete proof of the same key and witness (%.2f GB zkey image copied out of HBM), r = s = 0; C "
+                      "oracle orc_prove (oracle/c: single-threaded buildABC + NTT chain, then five Pippenger MSMs threaded "
+                      "over (window, chunk) tasks) on %d threads = this job's share of the box (nproc = %d); proof bytes equal "
+                      "to the GPU's. Reference log, other hardware: rapidsnark 2.56 s at the 1-sig layer-one shape (same 2^21 domain) on ~22 busy x86 cores "
+                      "(tests/1_sigs_1_batches_5_height/logs/layers_one_two_prove_batch_0.log:16-18)"
+                      % (len(zkey) / 1e9, cores, box_cores()),
+            "seconds": tcpu}
+
+
+def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial=False):
     """Full Groth16 prove against a key + witness resident in HBM. N>1: the proof's five MSMs are sharded
     over the ranks (BASELINE.json configs[3..4]); the H-scalar chain is split or replicated."""
     import torch
@@ -329,14 +415,19 @@ def prove_leg(env, k, steps, warmup, precompute=True):
                                       header, zk.sum_partials, zk.prove_assemble, 0, 0, dist, args.cdev)
 
     names = ("H", "A", "B1", "B2", "C")
+    proofs_run = 0
     try:
+        if serial:      # profiling runs (rocprofv3 --pmc): one stage at a time, so per-kernel counters are solo values
+            ctx.set_option("prove_serial", 1)
         if precompute:
             # fixed-base tables, once, outside the timed region -- after one proof, as the prover's own key cache does
             # (second use of a key): the A / B / C tables are then sized for the digit density of a real witness
             one_proof()
             table_bytes = circ.key.precompute()
+            proofs_run += 1
         for _ in range(warmup):
             one_proof()
+        proofs_run += warmup + steps
         env.sync()
         t0 = time.perf_counter()
         acc = {"h_chain": 0.0, "msm_phase": 0.0, "prove": 0.0, "h_msm_accum": 0.0}
@@ -357,6 +448,7 @@ def prove_leg(env, k, steps, warmup, precompute=True):
         solo = None
         if world == 1:
             ctx.set_option("prove_serial", 1)
+            proofs_run += 2
             try:
                 solo = {"h_chain": 0.0}
                 solo.update({"msm_%s" % x: 0.0 for x in names})
@@ -367,29 +459,34 @@ def prove_leg(env, k, steps, warmup, precompute=True):
                     for lane, x in enumerate(names):
                         solo["msm_%s" % x] += ctx.last_ms_lane(lane, 0) / 2
             finally:
-                ctx.set_option("prove_serial", 0)
+                ctx.set_option("prove_serial", 1 if serial else 0)
 
         # ---- correctness of what was timed: pi_a, pi_b AND pi_c against the known-dlog expectation. The H scalars
         # the GPU produced are read back and validated independently of any transform by the oracle's quotient
         # identity A(z)B(z) - C(z) = H(z)(z^n - 1) at a random point (oracle/c: orc_quotient_check).
-        ok, checked = True, "pi_a, pi_b by known discrete log"
-        if world == 1:
-            from oracle import c_oracle as co
-            P = circ.h_scalars()
+        # N > 1: every rank's H scalars (its cyclic shard after the split chain, its index range of the replicated
+        # chain -- what its H MSM actually consumed) are gathered and checked on rank 0, so pi_c is covered on the
+        # real multi-process path too.
+        from oracle import c_oracle as co
+        P = gather_h_scalars(env, circ, split)
+        ok, tq, threads = True, 0.0, min(32, host_cores())
+        if rank == 0:
             zpt = random.Random(0xC0FFEE + k).randrange(R_MOD)
-            threads = min(32, host_cores())
             tq = time.perf_counter()
             ok = co.quotient_check(circ.coeff_section(), circ.w_limbs, m, k, P, zpt, threads)
             tq = time.perf_counter() - tq
             ok = ok and circ.check(pts, 0, 0, P)
-            checked = ("pi_a, pi_b, pi_c by known discrete log; the 2^%d H scalars by the oracle's quotient identity at a "
-                       "random point (%.1f s on %d host threads)" % (k, tq, threads))
-        else:
-            ok = circ.check(pts, 0, 0)
+        checked = ("pi_a, pi_b, pi_c by known discrete log; the 2^%d H scalars%s by the oracle's quotient identity at a "
+                   "random point (%.1f s on %d host threads)"
+                   % (k, " (gathered from the %d ranks)" % world if world > 1 else "", tq, threads))
         env.agree(ok, "proof failed the known-dlog / quotient-identity check")
+        cpu = cpu_prove_baseline(env, circ, pts) if (cpu_baseline and world == 1) else None
     except BaseException:
         circ.close()
         raise
+    finally:
+        if serial:
+            ctx.set_option("prove_serial", 0)
 
     line = None
     if rank == 0:
@@ -398,9 +495,10 @@ def prove_leg(env, k, steps, warmup, precompute=True):
         # SURVEY.md 8d full-prove formula
         alg = 96 * (3 * m - n_pub - 1) + 160 * m + 96 * n + 6 * 64 * n + 76 * ncoef + 96 * n + 128 * n
         sec = elapsed / steps
+        traffic, tsrc = pmc_traffic("prove_2p%d" % k, "per_proof") if world == 1 else (None, None)
         roof = {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
                 "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes": alg,
                 "phase_ms_overlapped": {kk: v / steps for kk, v in acc.items()}}
         if solo is not None:
@@ -417,7 +515,7 @@ def prove_leg(env, k, steps, warmup, precompute=True):
                                                    "collectives; not a measurement)" if args.rehearse else ""),
             "config": {"workload": "full Groth16 prove, domain 2^%d, %d wires, %d public (%s); key and witness "
                                    "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
-                       "n_coefs": ncoef,
+                       "n_coefs": ncoef, "proofs_run_in_process": proofs_run,
                        "fixed_base_tables_GB": table_bytes / 1e9,
                        "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
                                        "points; H-scalar chain %s" % (world, "split (four-step NTTs, 2 all-to-alls per "
@@ -425,6 +523,8 @@ def prove_leg(env, k, steps, warmup, precompute=True):
                        "checked": checked},
             "roofline": roof,
         }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
     circ.close()
     del circ, xbufs
     torch.cuda.empty_cache()
@@ -527,7 +627,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="msm_g1_2p20")
+    ap.add_argument("--workload", default=None,
+                    help="default: msm_g1_2p20 with --gpus 1 (BASELINE.json configs[1]); prove_2p26 with --gpus N > 1 "
+                         "(configs[4]: ONE synthetic layer_one 2^26 proof sharded over the N GPUs, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="headline workload only (no 'also' legs)")
     ap.add_argument("--fixed-base", action="store_true", help="msm workloads: fixed-base form (precomputed table)")
@@ -535,7 +637,13 @@ def main():
     ap.add_argument("--replicated-chain", action="store_true",
                     help="prove workloads, N > 1: run the whole H-scalar chain on every rank instead of splitting it")
     ap.add_argument("--inflight", type=int, default=6, help="MSMs kept in flight on separate HIP streams (1..12)")
+    ap.add_argument("--serial", action="store_true",
+                    help="prove workloads: run the stages of every proof one after the other (profiling: per-kernel "
+                         "counters are then solo values); never a throughput measurement")
     args = ap.parse_args()
+    default_workload = args.workload is None
+    if default_workload:
+        args.workload = "msm_g1_2p20" if args.gpus == 1 else "prove_2p26"
 
     import torch
     import torch.distributed as dist
@@ -579,7 +687,8 @@ def main():
             env.ctx.set_option("msm_k0", int(os.environ["ZKPOA_MSM_K0"]))
         if args.workload.startswith("prove_2p"):
             line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
-                             precompute=not args.no_precompute)
+                             precompute=not args.no_precompute, serial=args.serial,
+                             cpu_baseline=(world == 1 and not args.no_cpu_baseline and args.workload == "prove_2p21"))
         elif args.workload.startswith("merkle_"):
             spec = args.workload[len("merkle_"):]            # merkle_10000000, merkle_1e7, merkle_10M, merkle_64k
             mult = {"k": 10**3, "K": 10**3, "M": 10**6}.get(spec[-1:], 1)
@@ -596,7 +705,8 @@ def main():
                     ("msm_g1_2p20_fixed_base", lambda: msm_leg(env, 20, args.steps, args.warmup, args.inflight, fixed_base=True)),
                     ("msm_g1_2p26", lambda: msm_leg(env, 26, 5, 2, 3)),
                     ("msm_g1_2p26_fixed_base", lambda: msm_leg(env, 26, 5, 2, 3, fixed_base=True)),
-                    ("prove_2p21", lambda: prove_leg(env, 21, 20, 3)),
+                    ("prove_2p21", lambda: prove_leg(env, 21, 20, 3, cpu_baseline=not args.no_cpu_baseline)),
+                    ("prove_2p25", lambda: prove_leg(env, 25, 4, 1)),
                     ("prove_2p26", lambda: prove_leg(env, 26, 3, 1)),
                     ("merkle_10M", lambda: merkle_leg(env, 10_000_000, 3, 1))):
                 t0 = time.perf_counter()
@@ -607,7 +717,26 @@ def main():
                 entry["leg_seconds"] = time.perf_counter() - t0
                 also.append(entry)
             line["also"] = also
+        # N > 1 with the driver's command line: the headline is the north-star's strong-scaling proof; the weak-scaling
+        # MSM of BASELINE.json configs[1] (2^20 points per GPU, all-gather of the partial points) rides along
+        if world > 1 and default_workload and not args.no_also:
+            t0 = time.perf_counter()
+            leg = msm_leg(env, 20, args.steps, args.warmup, args.inflight)
+            if rank == 0:
+                entry = {"workload": "msm_g1_2p20 (weak scaling, 2^20 points per GPU)"}
+                entry.update({kk: leg[kk] for kk in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling",
+                                                      "config", "roofline") if kk in leg})
+                entry["leg_seconds"] = time.perf_counter() - t0
+                line["also"] = [entry]
         if rank == 0:
+            line["n_ranks_seen"] = dist.get_world_size() if dist.is_initialized() else 1
+            if dist.is_initialized():
+                line["collectives"] = dist.get_backend()
+                if dist.get_backend() == "nccl":
+                    try:
+                        line["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                    except Exception:
+                        pass
             print(json.dumps(line), flush=True)
     except BenchError as e:
         sys.stderr.write("bench.py: %s\n" % e)

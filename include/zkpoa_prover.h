@@ -34,6 +34,10 @@ extern "C" {
 #define PROVER_ERROR 0x1
 #define PROVER_ERROR_SHORT_BUFFER 0x2
 #define PROVER_INVALID_WITNESS_LENGTH 0x3
+/* Extension (not in rapidsnark): the failure came from the HIP runtime (sticky GPU fault, lost device, out of device or
+ * host memory), not from the inputs -- the process's GPU context cannot be trusted any more. Returned by the two
+ * groth16_prover* entry points; callers that only test != PROVER_OK are unaffected. */
+#define PROVER_ERROR_RUNTIME 0x4
 
 /* ---- one-shot prove: replaces the process exec'd at scripts/g16_prove.sh:248-252 -------- */
 /* zkey / wtns are complete file images. proof_buffer / public_buffer receive NUL-terminated

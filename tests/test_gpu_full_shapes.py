@@ -6,8 +6,14 @@ above 2^16"):
   the H scalars the GPU chain produced (buildABC -> 6 NTTs -> joinABC) are compared bit for bit with the C
   oracle's and, independently of any transform, through the oracle's quotient identity.
 * G2 MSM at 2^20 (three-pass sort + short G2 pieces), known discrete log.
+* configs[3] shapes (N = 1): layer_two(2, 12) -- n = 2^25, 21,356,921 wires, 2 public -- and layer_three(2) --
+  n = 2^26, 52,367,163 wires, 13 public (tests/4_sigs_2_batches_12_height/benchmarks.txt:33-39, 49-55), same checks.
 * configs[4] (N = 1): 2^26 MSM and the synthetic layer_one(128 sigs) prove, same checks (about a minute on the GPU
-  box, ~25 GB of host memory; ZKPOA_SKIP_2P26=1 skips them; bench.py runs the same checks on its 2^26 lines).
+  box, ~25 GB of host memory; ZKPOA_SKIP_2P26=1 skips the 2^25 / 2^26 cases; bench.py runs the same checks on its
+  2^26 lines).
+
+Every expected group element is computed with the ORACLE's scalar multiplication (oracle/py/bn254.py), never with the
+product's own host code.
 """
 import os
 import random
@@ -46,11 +52,14 @@ def _prove_and_check_all(ctx, zk, k, m, n_public, seed, oracle_h):
         if oracle_h:                                           # bit-exact against the oracle's transform-based chain
             want = co.h_scalars(circ.coeff_section_bytes(), circ.witness_bytes(), m, k)
             assert P.tobytes() == want
-        assert circ.check(pts, r_, s_, P), "pi_a / pi_b / pi_c differ from the known-dlog expectation"
-        assert circ.check(pts, r_, s_, None)
+        a, b, c = circ.expected_dlogs(r_, s_, P)               # discrete logs: integer arithmetic only
+        assert g16.g1_from_bytes(pts, 0) == bn.g1_mul(bn.G1_GEN, a), "pi_a differs from the known-dlog expectation"
+        assert g16.g2_from_bytes(pts, 64) == bn.g2_mul(bn.G2_GEN, b), "pi_b differs from the known-dlog expectation"
+        assert g16.g1_from_bytes(pts, 192) == bn.g1_mul(bn.G1_GEN, c), "pi_c differs from the known-dlog expectation"
+        assert circ.check(pts, r_, s_, P)                      # the product-side check bench.py's N > 1 path uses agrees
         wrong = bytearray(pts)
         wrong[192] ^= 1
-        assert not circ.check(bytes(wrong), r_, s_, P)         # the check does look at pi_c
+        assert not circ.check(bytes(wrong), r_, s_, P)         # ... and does look at pi_c
         assert pub == circ.witness_bytes()[32:32 * (1 + n_public)]
         print("2^%d prove: quotient identity x2 in %.1f s on %d threads" % (k, t_q, THREADS))
     finally:
@@ -88,6 +97,18 @@ def test_msm_g1_2p26_known_dlog(ctx, zk):
     out = ctx.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)
     s0, s1 = dlog_sums(limbs)
     assert g16.g1_from_bytes(out) == bn.g1_mul(bn.G1_GEN, (a * s0 + b * s1) % R)
+
+
+@needs_2p26
+def test_prove_layer_two_shape_all_points(ctx, zk):
+    """BASELINE.json configs[3], layer two: L2(2, 12), tests/4_sigs_2_batches_12_height/benchmarks.txt:33-39."""
+    _prove_and_check_all(ctx, zk, 25, 21356921, 2, 0x5EED0025, oracle_h=False)
+
+
+@needs_2p26
+def test_prove_layer_three_shape_all_points(ctx, zk):
+    """BASELINE.json configs[3], layer three: L3(2), 13 public signals, tests/4_sigs_2_batches_12_height/benchmarks.txt:49-55."""
+    _prove_and_check_all(ctx, zk, 26, 52367163, 13, 0x5EED0026, oracle_h=False)
 
 
 @needs_2p26

@@ -56,6 +56,23 @@ def test_reference_anonymity_set_root(ctx):
         tree.close()
 
 
+def test_reference_merkle_path_fixture(ctx):
+    """The sibling path the reference's Rust binary produced for leaf 3 of that set and fed to its layer-two circuit
+    (tests/1_sigs_1_batches_5_height/layer_two/batch_0/layer_two_batch_0_input.json path_elements / path_indices)."""
+    from test_poseidon_oracle import ref_path_fixture
+    leaf_addr, leaf_bal, root, elems, bits = ref_path_fixture()
+    addr, bal = anon_set()
+    idx = addr.index(leaf_addr)
+    assert bal[idx] == leaf_bal
+    tree = ctx.merkle_build(b"".join(le(a) for a in addr), b"".join(le(b) for b in bal))
+    try:
+        assert tree.root() == root
+        assert tree.path(idx) == (elems, bits)
+        assert _ints(tree.leaves())[idx] == P.poseidon([leaf_addr, leaf_bal])
+    finally:
+        tree.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 4097])
 def test_tree_vs_c_oracle(ctx, n):
     rng = random.Random(n)

@@ -713,6 +713,9 @@ def test_multi_process_sharded_prove_rehearsal(nproc, extra):
     assert line["n_gpus"] == nproc and line["metric"] == "Groth16 proofs/sec"
     assert ("replicated" if extra else "split") in line["config"]["parallelism"]
     assert "REHEARSAL" in line["data"]
+    # the real multi-process path checks pi_c too: the ranks' H scalars are gathered and validated on rank 0
+    assert "pi_c" in line["config"]["checked"] and "gathered from the %d ranks" % nproc in line["config"]["checked"]
+    assert line["n_ranks_seen"] == nproc
 
 
 # ---- failure paths that used to be silent or sticky ---------------------------------------------------
@@ -737,6 +740,36 @@ def test_server_death_mid_request_still_yields_the_proof(zk, tmp_path):
         rc = subprocess.run(argv, env=env, capture_output=True, text=True, cwd=tmp_path, timeout=120)
         assert rc.returncode == 0 and "prover server pid" in rc.stderr, rc.stderr
         assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
+def test_server_failure_is_logged_and_strict_mode_refuses_the_fallback(zk, tmp_path):
+    """the in-process fallback must never hide a GPU-side failure. When the server dies with a
+    request in hand the client still proves (exit 0) but leaves a line in the persistent fault log and names it on
+    stderr; with ZKPOA_STRICT=1 the same event is exit != 0 and no proof is written."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    sock = str(tmp_path / "prover.sock")
+    log = "/tmp/zkpoa-%d/faults.log" % os.getuid()
+    before = os.path.getsize(log) if os.path.exists(log) else 0
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60",
+               ZKPOA_SERVER_TEST_CRASH="1")
+    argv = [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"]
+    try:
+        rc = subprocess.run(argv, env=env, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert rc.returncode == 0, rc.stderr
+        assert log in rc.stderr and (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+        new = open(log).read()[before:]
+        assert "went away without answering" in new and str(tmp_path / "circuit_final.zkey") in new
+        os.remove(tmp_path / "proof.json")
+        os.remove(tmp_path / "public.json")
+        rc = subprocess.run(argv, env=dict(env, ZKPOA_STRICT="1"), capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert rc.returncode == 5 and "ZKPOA_STRICT" in rc.stderr, rc.stderr
+        assert not (tmp_path / "proof.json").exists() and not (tmp_path / "public.json").exists()
+        assert open(log).read().count("went away without answering", before) >= 2
     finally:
         subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
 

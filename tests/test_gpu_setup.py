@@ -272,6 +272,54 @@ def test_zkey_contribute_equals_the_setup_with_that_delta(ctx, zk, tmp_path):
         ctx.zkey_contribute(tmp_path / "c_0.zkey", tmp_path / "x.zkey", R)
 
 
+def test_setup_outputs_are_atomic_and_inputs_range_checked(ctx, zk, tmp_path):
+    """(1) zkey new / contribute write <path>.tmp.<pid> and rename: a failing run leaves nothing under the
+    final name (and no temporary); contributing IN PLACE (in == out) works; (2) a ptau / zkey coordinate >= q is
+    rejected instead of flowing into a well-formed but wrong key."""
+    from oracle.py import groth16 as g16
+    from setup_files import write_ptau
+    rng = random.Random(77)
+    n_vars, n_public, n_cons = 40, 1, 50
+    cons, w, tox, want0, vk, r1cs, power = _setup_case(rng, n_vars, n_public, n_cons)
+    ptau = write_ptau(power, tox["tau"], tox["alpha"], tox["beta"])
+    (tmp_path / "c.r1cs").write_bytes(r1cs)
+    (tmp_path / "pot.ptau").write_bytes(ptau)
+    # unwritable destination: error, nothing left behind
+    with pytest.raises(zk.ZkpoaError):
+        ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "pot.ptau", tmp_path / "no_such_dir" / "c.zkey")
+    ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "pot.ptau", tmp_path / "c.zkey")
+    assert (tmp_path / "c.zkey").read_bytes() == want0
+    # in place: the output replaces the input atomically
+    d1 = rng.randrange(1, R)
+    ctx.zkey_contribute(tmp_path / "c.zkey", tmp_path / "c.zkey", d1)
+    fb1 = lambda s: co.fixed_base_g1(b"".join(le(k) for k in s), 8)
+    fb2 = lambda s: co.fixed_base_g2(b"".join(le(k) for k in s), 8)
+    want1, _ = g16.synthetic_setup(n_vars, n_public, cons, dict(tox, delta=d1), g1_batch=fb1, g2_batch=fb2)
+    assert (tmp_path / "c.zkey").read_bytes() == want1
+    assert sorted(x.name for x in tmp_path.iterdir()) == ["c.r1cs", "c.zkey", "pot.ptau"]      # no *.tmp.* anywhere
+    # a Lagrange-form ceremony point with x = q (not canonical): rejected, and no key appears
+    secs = {t: lst[0] for t, lst in g16.read_binfile(ptau, "ptau", 1).items()}
+    Q = bn.Q
+    for sec_id in (12, 13, 14, 15):
+        off, ln = secs[sec_id]
+        bad = bytearray(ptau)
+        unit = 128 if sec_id == 13 else 64
+        at = off + ((1 << power) - 1) * unit                                   # first point of the circuit's level
+        bad[at:at + 32] = le(Q)
+        (tmp_path / "bad.ptau").write_bytes(bytes(bad))
+        with pytest.raises(zk.ZkpoaError, match="field element"):
+            ctx.zkey_new(tmp_path / "c.r1cs", tmp_path / "bad.ptau", tmp_path / "bad.zkey")
+        assert not (tmp_path / "bad.zkey").exists()
+    # ... and the same for a point of section 9 of a key handed to contribute
+    zsecs = {t: lst[0] for t, lst in g16.read_binfile(want0, "zkey", 1).items()}
+    badk = bytearray(want0)
+    badk[zsecs[9][0]:zsecs[9][0] + 32] = le(Q + 1)
+    (tmp_path / "badk.zkey").write_bytes(bytes(badk))
+    with pytest.raises(zk.ZkpoaError, match="field element"):
+        ctx.zkey_contribute(tmp_path / "badk.zkey", tmp_path / "out.zkey", 3)
+    assert not (tmp_path / "out.zkey").exists()
+
+
 # ---- `snarkjs wtns check` -------------------------------------------------------------------------------------------
 def test_wtns_check(ctx, zk, tmp_path):
     import subprocess

@@ -41,6 +41,38 @@ def test_reference_merkle_root_python_oracle():
     assert node == REF_ROOT
 
 
+def ref_path_fixture():
+    """The Merkle inputs of the reference's layer-two circuit for this set (tests/1_sigs_1_batches_5_height/layer_two/
+    batch_0/layer_two_batch_0_input.json: leaf_addresses, leaf_balances, merkle_root, path_elements, path_indices)."""
+    d = json.load(open(os.path.join(GOLDEN, "ref", "merkle", "layer_two_batch_0_merkle_inputs.json")))
+    return (int(d["leaf_addresses"][0]), int(d["leaf_balances"][0]), int(d["merkle_root"]),
+            [int(x) for x in d["path_elements"][0]], [int(x) for x in d["path_indices"][0]])
+
+
+def test_reference_merkle_path_fixture_oracles():
+    """The sibling path the reference fed to its layer-two circuit (produced by its Rust binary, merkle_tree.rs:354-376)
+    equals the Python oracle's and the C oracle's path for that leaf, and folds to the logged root."""
+    leaf_addr, leaf_bal, root, elems, bits = ref_path_fixture()
+    addr, bal = anon_set()
+    assert root == REF_ROOT
+    idx = addr.index(leaf_addr)
+    assert idx == 3 and bal[idx] == leaf_bal
+    levels = P.merkle_levels(addr, bal)
+    assert P.merkle_path(levels, idx) == (elems, bits)
+    lv = co.merkle_levels(b"".join(le(a) for a in addr), b"".join(le(b) for b in bal), 4, 2)
+    node_at = lambda level, i: int.from_bytes(lv[32 * ((32 - (32 >> level)) + i):][:32], "little")   # levels 16, 8, 4, 2, 1
+    i, got_e, got_b = idx, [], []
+    for level in range(4):
+        got_e.append(node_at(level, i ^ 1))
+        got_b.append(i & 1)
+        i >>= 1
+    assert (got_e, got_b) == (elems, bits)
+    node = P.poseidon([leaf_addr, leaf_bal])
+    for e, bit in zip(elems, bits):
+        node = P.poseidon([e, node] if bit else [node, e])
+    assert node == root
+
+
 def test_c_oracle_equals_python_oracle():
     rng = random.Random(7)
     xs = [0, 1, P.R - 1, 2 ** 160 - 1] + [rng.randrange(P.R) for _ in range(12)]

@@ -23,6 +23,7 @@ PROVER_OK = 0
 PROVER_ERROR = 1
 PROVER_ERROR_SHORT_BUFFER = 2
 PROVER_INVALID_WITNESS_LENGTH = 3
+PROVER_ERROR_RUNTIME = 4
 
 # every symbol include/zkpoa_prover.h declares
 EXPORTS = [
@@ -226,7 +227,10 @@ class Context:
     def stream(self, lane=0):
         """The HIP stream of a lane as an integer handle (wrap with torch.cuda.ExternalStream to order torch work /
         RCCL collectives with the library's kernels without host synchronisation)."""
-        return int(lib().zkpoa_context_stream(self._h, lane) or 0)
+        h = int(lib().zkpoa_context_stream(self._h, lane) or 0)
+        if h == 0:      # 0 would silently become the legacy default stream in torch.cuda.ExternalStream
+            raise ZkpoaError("zkpoa_context_stream: no stream for lane %d" % lane)
+        return h
 
     def synchronize(self):
         """Wait for lane 0's stream (the split-chain stages only enqueue)."""

@@ -453,7 +453,8 @@ extern "C" int zkpoa_merkle_root(zkpoa_context* ctx, const zkpoa_merkle* tree, u
 extern "C" int zkpoa_merkle_leaves(zkpoa_context* ctx, const zkpoa_merkle* tree, uint64_t first, uint64_t count, void* out) {
   if (!tree || !out) return PROVER_ERROR;
   ZK_API_BEGIN(ctx)
-  if (first + count > (1ull << tree->log_leaves)) throw HipError("merkle: leaf range out of bounds");
+  const uint64_t n_leaves = 1ull << tree->log_leaves;
+  if (first > n_leaves || count > n_leaves - first) throw HipError("merkle: leaf range out of bounds");
   ZK_HIP(hipMemcpy(out, reinterpret_cast<const char*>(tree->d_levels) + first * 32, count * 32, hipMemcpyDeviceToHost));
   ZK_API_END(ctx)
 }

@@ -24,6 +24,7 @@
 #include <memory>
 #include <map>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 using namespace zkpoa;
@@ -1396,6 +1397,15 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
+  } catch (const HipError& e) {            // HIP runtime failure: the context is suspect (PROVER_ERROR_RUNTIME)
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::bad_alloc&) {
+    set_err(error_msg, error_msg_maxsize, "out of host memory");
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::system_error& e) {   // a stage thread could not be started
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
   } catch (const std::exception& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = PROVER_ERROR;
@@ -1542,6 +1552,15 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
+  } catch (const HipError& e) {            // HIP runtime failure: the context and its cached keys are suspect
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::bad_alloc&) {
+    set_err(error_msg, error_msg_maxsize, "out of host memory");
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::system_error& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
   } catch (const std::exception& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = PROVER_ERROR;
@@ -1715,6 +1734,7 @@ extern "C" void* zkpoa_context_stream(zkpoa_context* ctx, int lane) {
   if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes) return nullptr;
   try {
     if (lane) ctx->dev.wait_lanes();
+    ctx->dev.ensure_lane(lane);   // lanes beyond the eager ones are created on first use: never hand out a null stream
   } catch (const std::exception&) {
     return nullptr;
   }

@@ -105,8 +105,8 @@ static int prove_files(const char* zkey, const char* wtns_path, const char* proo
   }
   if (rc != PROVER_OK) {
     message = std::string("Error: ") + err;
-    // the library's HIP failures read "<hip call> failed: <hipGetErrorString> at file:line" (device_ctx.hpp ZK_HIP)
-    if (runtime_failure) *runtime_failure = strstr(err, " failed: ") && strstr(err, "hip");
+    // the library tells HIP-runtime failures (sticky fault, lost device, out of memory) from input errors by code
+    if (runtime_failure) *runtime_failure = rc == PROVER_ERROR_RUNTIME;
     return EXIT_FAILURE;
   }
   if (!write_atomic(proof_path, proof.data()) || !write_atomic(public_path, pub.data())) {
@@ -115,6 +115,41 @@ static int prove_files(const char* zkey, const char* wtns_path, const char* proo
   }
   return EXIT_SUCCESS;
 }
+
+// ---- the fault log ---------------------------------------------------------------------------------------
+// A GPU fault must never pass unnoticed because a fallback produced the proof anyway (r02: a memory access fault inside
+// the resident server was only found by counting lines of its log). Whenever this process proves in-process BECAUSE the
+// server failed -- it reported a HIP runtime failure, died, or did not answer -- one line goes to a persistent log
+// /tmp/zkpoa-<uid>/faults.log (time, pid, what happened, the key) and its path to stderr. ZKPOA_STRICT=1 turns the
+// fallback into a non-zero exit instead (the workflow's ERR trap fires and somebody looks at the machine).
+static std::string fault_log_path() {
+  return "/tmp/zkpoa-" + std::to_string((long)getuid()) + "/faults.log";
+}
+static void log_fault(const char* what, const std::string& detail, const char* zkey) {
+  const std::string path = fault_log_path();
+  const std::string dir = path.substr(0, path.rfind('/'));
+  (void)mkdir(dir.c_str(), 0700);
+  char when[64] = {0};
+  time_t now = time(nullptr);
+  struct tm tmv;
+  gmtime_r(&now, &tmv);
+  strftime(when, sizeof(when), "%Y-%m-%dT%H:%M:%SZ", &tmv);
+  std::string line = std::string(when) + " pid " + std::to_string((long)getpid()) + " " + what + ": " + detail +
+                     " | zkey " + (zkey ? zkey : "-") + "\n";
+  for (char& c : line)
+    if ((c == '\n' || c == '\r') && &c != &line[line.size() - 1]) c = ' ';
+  int fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND | O_CLOEXEC, 0600);
+  if (fd >= 0) {
+    (void)!write(fd, line.data(), line.size());   // O_APPEND: one write per line, concurrent provers do not interleave
+    close(fd);
+  }
+  fprintf(stderr, "zkpoa: GPU-side failure recorded in %s\n", path.c_str());
+}
+static bool strict_mode() {
+  const char* e = getenv("ZKPOA_STRICT");
+  return e && *e && strcmp(e, "0") != 0;
+}
+enum { kExitStrict = 5 };   // ZKPOA_STRICT=1: the server failed and the fallback was refused
 
 // ---- server mode ---------------------------------------------------------------------------------------
 // Wire format, both directions: u32 length + payload. Request payload = NUL-separated fields
@@ -204,6 +239,10 @@ static int server_main(const std::string& sock) {
   std::string lockp = sock + ".lock";
   int lock = open(lockp.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
   if (lock < 0 || flock(lock, LOCK_EX | LOCK_NB) != 0) return 0;   // another server owns this socket
+  {   // our pid, for a client that has to end a wedged server (kept in the lock file: only its holder writes it)
+    const std::string pid = std::to_string((long)getpid()) + "\n";
+    if (ftruncate(lock, 0) == 0) (void)!pwrite(lock, pid.data(), pid.size(), 0);
+  }
   unlink(sock.c_str());                                           // stale socket of a dead server
   int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
   struct sockaddr_un sa;
@@ -347,16 +386,43 @@ static int client_main(char** argv, const std::string& sock, bool stop) {
     struct timeval tv = {to, 0};
     (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
   }
+  errno = 0;
   if (!send_msg(fd, req) || !recv_msg(fd, reply) || reply.empty()) {
     // no reply arrived (the server died, or was exiting when we connected): nothing has been written, so this
     // process can simply do the work itself
+    const bool timed_out = errno == EAGAIN || errno == EWOULDBLOCK;
     close(fd);
     if (stop) return EXIT_SUCCESS;
+    // A server that is still alive here is wedged (or was leaving): it may hold tens of GB of cached keys in HBM and may
+    // still be writing the same output paths. End it -- the pid it left in its lock file, same uid -- before this
+    // process takes the GPU. Never a re-exec: this process proves itself, a later call starts a fresh server.
+    long spid = 0;
+    if (FILE* lf = fopen((sock + ".lock").c_str(), "r")) {
+      if (fscanf(lf, "%ld", &spid) != 1) spid = 0;
+      fclose(lf);
+    }
+    bool killed = false;
+    if (spid > 1 && spid != (long)getpid() && kill((pid_t)spid, 0) == 0) {
+      killed = kill((pid_t)spid, SIGKILL) == 0;
+      for (int i = 0; killed && i < 100 && kill((pid_t)spid, 0) == 0; i++) usleep(20000);
+    }
+    log_fault(timed_out ? "prover server did not answer in time" : "prover server went away without answering",
+              std::string("server pid ") + std::to_string(spid) + (killed ? " (killed)" : " (gone)"), argv[1]);
+    if (strict_mode()) {
+      fprintf(stderr, "zkpoa: the prover server went away without answering; ZKPOA_STRICT is set: not proving in-process\n");
+      return kExitStrict;
+    }
     fprintf(stderr, "zkpoa: the prover server went away without answering; proving in-process\n");
     return -1;
   }
   close(fd);
   if (reply[0] == 'R') {
+    log_fault("prover server reported a GPU runtime failure", reply.substr(1), argv[1]);
+    if (strict_mode()) {
+      fprintf(stderr, "zkpoa: the prover server reported a GPU runtime failure (%s); ZKPOA_STRICT is set: not proving "
+                      "in-process\n", reply.c_str() + 1);
+      return kExitStrict;
+    }
     fprintf(stderr, "zkpoa: the prover server reported a GPU runtime failure (%s) and is restarting; proving in-process\n",
             reply.c_str() + 1);
     return -1;
@@ -386,9 +452,11 @@ int main(int argc, char** argv) {
     // no server reachable: prove in this process (still on the GPU)
   }
   std::string message;
-  int rc = prove_files(argv[1], argv[2], argv[3], argv[4], message);
+  bool runtime_failure = false;
+  int rc = prove_files(argv[1], argv[2], argv[3], argv[4], message, &runtime_failure);
   if (rc != EXIT_SUCCESS) {
     fprintf(stderr, "%s\n", message.c_str());
+    if (runtime_failure) log_fault("in-process prove hit a HIP runtime failure", message, argv[1]);
     return rc;
   }
   if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: prover process total %.1f ms\n", now_ms() - t_start);

@@ -18,6 +18,7 @@
 //   3. the MSM's partial-sum levels (msm_accumN_kernel, fan-in 4: a hot segment is a chain of full additions, so
 //      depth matters) until every segment is one point; 4. XYZZ -> affine, zkey wire format.
 // The order inside a segment depends on the atomics; the sum does not, and the affine output is canonical.
+#include "abc.hip.h"
 #include "msm.hip.h"
 #include "hooks.hip.h"
 #include "zkpoa_internal.hpp"
@@ -371,6 +372,61 @@ struct MappedFile {
   MappedFile& operator=(const MappedFile&) = delete;
 };
 
+// Output files are written under a temporary name and renamed into place (as prover_main's write_atomic): a failure
+// part-way (ENOSPC, HIP error, kill) never leaves a truncated .zkey under the final name for a later "skip if the zkey
+// exists" step to pick up, and writing over the input of `zkey contribute` is safe (the mapping keeps the old inode).
+struct AtomicFile {
+  std::string path, tmp;
+  FILE* f = nullptr;
+  bool ok = true;
+  explicit AtomicFile(const char* final_path) : path(final_path), tmp(path + ".tmp." + std::to_string((long)getpid())) {
+    f = fopen(tmp.c_str(), "wb");
+    if (!f) throw SetupError("cannot create " + tmp);
+  }
+  void write(const void* p, size_t len) {
+    if (ok && len) ok = fwrite(p, 1, len, f) == len;
+  }
+  void commit() {
+    ok = (fclose(f) == 0) && ok;
+    f = nullptr;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+      unlink(tmp.c_str());
+      throw SetupError("write to " + path + " failed");
+    }
+  }
+  ~AtomicFile() {
+    if (f) {
+      fclose(f);
+      unlink(tmp.c_str());
+    }
+  }
+  AtomicFile(const AtomicFile&) = delete;
+  AtomicFile& operator=(const AtomicFile&) = delete;
+};
+
+// Untrusted inputs: the device keeps Fq elements lazily in [0, 2q) and takes file bytes raw, so every
+// coordinate that reaches a kernel or is copied into the key must be a canonical field element (< q).
+void host_check_coords(const uint8_t* p, uint64_t count32, const char* what) {
+  for (uint64_t i = 0; i < count32; i++) {
+    uint64_t v[4];
+    memcpy(v, p + 32 * i, 32);
+    if (v[3] >= HFqParams::P[3] && HFq::geq_p(v)) throw SetupError(std::string(what) + ": a coordinate is not a field element (>= q)");
+  }
+}
+void dev_check_coords(zkpoa_context* ctx, const void* d, uint64_t count32, const char* what) {
+  if (!count32) return;
+  hipStream_t st = ctx->dev.lanes[0].stream;
+  DevBuf flag(64);
+  ZK_HIP(hipMemsetAsync(flag.p, 0, 64, st));
+  hipLaunchKernelGGL((range_check_kernel<FqParams>), dim3((uint32_t)((count32 + 255) / 256)), dim3(256), 0, st, d, count32,
+                     (uint32_t*)flag.p);
+  uint32_t bad = 0;
+  ZK_HIP(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st));
+  ZK_HIP(hipStreamSynchronize(st));
+  ZK_HIP(hipGetLastError());
+  if (bad) throw SetupError(std::string(what) + ": a coordinate is not a field element (>= q)");
+}
+
 struct Sec {
   uint64_t off = 0, len = 0;
   bool present = false;
@@ -415,9 +471,10 @@ R1cs parse_r1cs(const MappedFile& f) {
   const uint8_t* q = f.p + h.off + 36;
   R1cs r;
   r.nWires = rd32(q);
-  r.nPublic = rd32(q + 4) + rd32(q + 8);   // outputs + public inputs
+  const uint64_t n_public = (uint64_t)rd32(q + 4) + rd32(q + 8);   // outputs + public inputs (no 32-bit wrap)
   r.nConstraints = rd32(q + 24);
-  if (r.nWires == 0 || (uint64_t)r.nPublic + 1 > r.nWires) throw SetupError("r1cs: inconsistent wire counts");
+  if (r.nWires == 0 || n_public + 1 > r.nWires) throw SetupError("r1cs: inconsistent wire counts");
+  r.nPublic = (uint32_t)n_public;
   uint64_t pos = cs.off;
   const uint64_t end = cs.off + cs.len;
   std::vector<Term> lc;
@@ -550,6 +607,10 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   pread_all(fp.fd, alpha1, 64, ps[4].off, "alpha*G1");
   pread_all(fp.fd, beta1, 64, ps[5].off, "beta*G1");
   pread_all(fp.fd, beta2, 128, ps[6].off, "beta*G2");
+  host_check_coords(alpha1, 2, "ptau alpha*G1");
+  host_check_coords(beta1, 2, "ptau beta*G1");
+  host_check_coords(beta2, 4, "ptau beta*G2");
+  host_check_coords(Hs.data(), 4 * n, "ptau tau*G1 (Lagrange, 2n)");   // copied into section 9 without touching the device
   phase("ptau ranges read");
 
   // entries of the three accumulations (+ the nPublic + 1 rows `1 * signal_i` that bind the public inputs)
@@ -567,12 +628,14 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   {
     DevArr dL1(n * 64);
     dL1.up(L1.data(), L1.size());
+    dev_check_coords(ctx, dL1.p, 2 * n, "ptau tau*G1 (Lagrange)");
     secA = run_accumulate<Fq>(ctx, dL1, n, eA, m);
     secB1 = run_accumulate<Fq>(ctx, dL1, n, eB, m);
   }
   {
     DevArr dL2(n * 128);
     dL2.up(L2.data(), L2.size());
+    dev_check_coords(ctx, dL2.p, 4 * n, "ptau tau*G2 (Lagrange)");
     secB2 = run_accumulate<Fq2>(ctx, dL2, n, eB, m);
   }
   {
@@ -580,6 +643,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     dK.up(bL.data(), n * 64, 0);
     dK.up(aL.data(), n * 64, n * 64);
     dK.up(L1.data(), n * 64, 2 * n * 64);
+    dev_check_coords(ctx, dK.p, 4 * n, "ptau alpha*tau*G1 / beta*tau*G1 (Lagrange)");
     secK = run_accumulate<Fq>(ctx, dK, 3 * n, eK, m);
   }
 
@@ -633,17 +697,16 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
                       {4, s4.data(), s4.size()}, {5, secA.data(), secA.size()}, {6, secB1.data(), secB1.size()},
                       {7, secB2.data(), secB2.size()}, {8, secK.data() + icb, secK.size() - icb},
                       {9, s9.data(), s9.size()}, {10, s10.data(), s10.size()}};
-  FILE* fo = fopen(zkey_path, "wb");
-  if (!fo) throw SetupError(std::string("cannot create ") + zkey_path);
-  bool ok = fwrite("zkey", 1, 4, fo) == 4;
+  AtomicFile fo(zkey_path);
+  fo.write("zkey", 4);
   const uint32_t hdr[2] = {1, 10};
-  ok = ok && fwrite(hdr, 4, 2, fo) == 2;
+  fo.write(hdr, 8);
   for (const Out& o : outs) {
-    ok = ok && fwrite(&o.id, 4, 1, fo) == 1 && fwrite(&o.len, 8, 1, fo) == 1;
-    ok = ok && (o.len == 0 || fwrite(o.p, 1, o.len, fo) == o.len);
+    fo.write(&o.id, 4);
+    fo.write(&o.len, 8);
+    fo.write(o.p, o.len);
   }
-  ok = (fclose(fo) == 0) && ok;
-  if (!ok) throw SetupError(std::string("write to ") + zkey_path + " failed");
+  fo.commit();
   phase("zkey written");
 }
 
@@ -749,6 +812,7 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
   memcpy(dinv_le, dinv.l, 32);
 
   std::vector<uint8_t> s2(fi.p + h.off, fi.p + h.off + h.len);
+  host_check_coords(&s2[kDelta1], 2 + 4, "zkey delta1 / delta2");
   {
     Affine<HFq> d1 = h_affine_from_bytes<HFq>(&s2[kDelta1]);
     Affine<HFq2> d2 = h_affine_from_bytes<HFq2>(&s2[kDelta2]);
@@ -760,27 +824,28 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
     if (sc.len) {
       DevArr in(sc.len), res(sc.len);
       in.up(fi.p + sc.off, sc.len);
+      dev_check_coords(ctx, in.p, sc.len / 32, "zkey C / H section");
       setup_scale<Fq>(ctx, in.p, sc.len / 64, dinv_le, res.p);
       ZK_HIP(hipMemcpy(out.data(), res.p, sc.len, hipMemcpyDeviceToHost));
     }
     return out;
   };
   const std::vector<uint8_t> s8 = scaled(secs[8]), s9 = scaled(secs[9]);
-  FILE* fo = fopen(out_path, "wb");
-  if (!fo) throw SetupError(std::string("cannot create ") + out_path);
-  bool ok = fwrite("zkey", 1, 4, fo) == 4;
+  AtomicFile fo(out_path);   // temporary name + rename: in_path == out_path is fine (the mapping keeps the old inode)
+  fo.write("zkey", 4);
   const uint32_t hdr[2] = {1, 10};
-  ok = ok && fwrite(hdr, 4, 2, fo) == 2;
+  fo.write(hdr, 8);
   for (uint32_t t = 1; t <= 10; t++) {
     const uint8_t* p = fi.p + secs[t].off;
     uint64_t len = secs[t].len;
     if (t == 2) p = s2.data();
     if (t == 8) p = s8.data();
     if (t == 9) p = s9.data();
-    ok = ok && fwrite(&t, 4, 1, fo) == 1 && fwrite(&len, 8, 1, fo) == 1 && (len == 0 || fwrite(p, 1, len, fo) == len);
+    fo.write(&t, 4);
+    fo.write(&len, 8);
+    fo.write(p, len);
   }
-  ok = (fclose(fo) == 0) && ok;
-  if (!ok) throw SetupError(std::string("write to ") + out_path + " failed");
+  fo.commit();
 }
 
 }  // namespace

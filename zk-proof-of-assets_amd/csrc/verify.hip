@@ -375,7 +375,8 @@ extern "C" int zkpoa_groth16_verify_points(const uint8_t* vkey_points, unsigned 
                                            unsigned long n_public, char* error_msg, unsigned long error_msg_maxsize) {
   try {
     if (!vkey_points || !proof_points || (n_public && !public_le)) throw std::runtime_error("null argument");
-    if (vkey_size != 448 + ((unsigned long)n_public + 1) * 64)
+    // bound n_public before multiplying: (2^58) * 64 wraps to 0 and would pass the size test
+    if (vkey_size < 448 + 64 || n_public != (vkey_size - 448) / 64 - 1 || (vkey_size - 448) % 64 != 0)
       throw std::runtime_error("vkey_points: expected alpha1(64) beta2(128) gamma2(128) delta2(128) + (nPublic+1) IC points");
     VKey vk;
     vk.alpha1 = h_affine_from_bytes<HFq>(vkey_points);

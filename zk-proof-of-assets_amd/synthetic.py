@@ -113,20 +113,34 @@ class SyntheticCircuit:
         r2 = (1 << 512) % R_MOD                           # coefficient 1 is stored as 1 * R^2
         val = torch.tensor([(r2 >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=torch.int64).to(torch.int32)
         n_coef = 3 * n_cons + n_public + 1
-        # host image of zkey section 4 (u32 count + 44-byte records) in one buffer; `recs` is a view of the records
-        self._sec4 = np.empty(4 + n_coef * 44, dtype=np.uint8)
-        self._sec4[:4] = np.frombuffer(int(n_coef).to_bytes(4, "little"), dtype=np.uint8)
-        recs = torch.from_numpy(self._sec4[4:].view(np.int32).reshape(n_coef, 11))
+        # host image of zkey section 4 (u32 count + 44-byte records) in one buffer; `recs` is a view of the records.
+        # A split shard other than rank 0 builds only the records of its own constraints c = rank (mod world): the full
+        # image (8.9 GB at 2^26) is needed on the device by nobody and on the host only by rank 0 (bench.py's checks).
+        own_only = bool(split) and rank != 0
+        if own_only:
+            cons = torch.arange(rank, n_cons, world, dtype=torch.int64)
+            pubs = torch.arange(n_cons, n_cons + n_public + 1, dtype=torch.int64)
+            pubs = pubs[(pubs % world) == rank]
+            n_host = 3 * cons.numel() + pubs.numel()
+        else:
+            cons = torch.arange(n_cons, dtype=torch.int64)
+            pubs = torch.arange(n_cons, n_cons + n_public + 1, dtype=torch.int64)
+            n_host = n_coef
+        self._sec4 = np.empty(4 + n_host * 44, dtype=np.uint8)
+        self._sec4[:4] = np.frombuffer(int(n_host).to_bytes(4, "little"), dtype=np.uint8)
+        recs = torch.from_numpy(self._sec4[4:].view(np.int32).reshape(n_host, 11))
         recs[:, 3:] = val
+        nc = cons.numel()
         for t, mat in enumerate((0, 0, 1)):
-            blk = recs[t * n_cons:(t + 1) * n_cons]
+            blk = recs[t * nc:(t + 1) * nc]
             blk[:, 0] = mat
-            blk[:, 1] = cidx
-            blk[:, 2] = sig[:, t]
-        pub = recs[3 * n_cons:]
+            blk[:, 1] = cons.to(torch.int32)
+            blk[:, 2] = sig[cons, t]
+        pub = recs[3 * nc:]
         pub[:, 0] = 0
-        pub[:, 1] = torch.arange(n_cons, n_cons + n_public + 1, dtype=torch.int32)
-        pub[:, 2] = torch.arange(0, n_public + 1, dtype=torch.int32)
+        pub[:, 1] = pubs.to(torch.int32)
+        pub[:, 2] = (pubs - n_cons).to(torch.int32)
+        self.sec4_complete = not own_only
         # wires present in A (both A-terms and the public rows) and in B: the others get the point at infinity
         in_a = torch.zeros(m, dtype=torch.bool)
         in_b = torch.zeros(m, dtype=torch.bool)
@@ -141,11 +155,12 @@ class SyntheticCircuit:
             self.d_B2[:wcnt * 128].view(wcnt, 128)[(~in_b[wlo:wlo + wcnt]).to(dev)] = 0
         self.n_coef = n_coef
         self.recs_host = recs                              # [n_coef, 11] int32 == 44-byte records
-        if split:                                          # only the records of this rank's constraints go to HBM
+        if split and not own_only:                         # only the records of this rank's constraints go to HBM
             mine = recs[(recs[:, 1] % world) == rank].contiguous()
             self.d_recs, n_dev = mine.to(dev), mine.shape[0]
+            del mine
         else:
-            self.d_recs, n_dev = recs.to(dev), n_coef
+            self.d_recs, n_dev = recs.to(dev), n_host
         # witness: w[0] = 1, rest uniform 252-bit (or witness-like: 55% bits, 35% < 2^64, 10% uniform)
         nr = np.random.default_rng(seed + 1)
         limbs = nr.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + nr.integers(0, 2, size=(m, 4), dtype=np.uint64)
@@ -175,6 +190,8 @@ class SyntheticCircuit:
 
     def coeff_section(self):
         """Payload of zkey section 4 (u32 count + records) as a numpy uint8 array (no copy)."""
+        if not self.sec4_complete:
+            raise RuntimeError("this rank's synthetic circuit holds only its own coefficient records")
         return self._sec4
 
     def coeff_section_bytes(self):
