@@ -399,8 +399,13 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
     # its cyclic H shard and its constraints' records: zkpoa_zkey_load_device_shard) and, like the single-GPU key,
     # gets the fixed-base tables of what it holds -- 1/N of the memory.
     split = world > 1 and not args.replicated_chain and sharding.split_chain_supported(world, 1 << k)
+    # sections 5-8 are dealt out block-cyclically (blocks of 2^16 wires; fewer for the test sizes so that every rank
+    # still holds several): a real witness clusters, equal index ranges would be unequal work
+    block_log = 16
+    while block_log > 4 and (m >> block_log) < 8 * world:
+        block_log -= 1
     circ = SyntheticCircuit(zk, ctx, k, m, n_public=n_pub, seed=0x5EED0010, witness_like=True,
-                            shard=(rank, world, split) if world > 1 else None)
+                            shard=(rank, world, split, block_log) if world > 1 else None)
     header = circ.key.header()
     xbufs = sharding.exchange_buffers(1 << k, world, env.dev) if split else None
     table_bytes = 0
@@ -517,8 +522,9 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
                                    "resident in HBM; witness-like scalar distribution" % (k, m, n_pub, what),
                        "n_coefs": ncoef, "proofs_run_in_process": proofs_run,
                        "fixed_base_tables_GB": table_bytes / 1e9,
-                       "parallelism": ("one proof, five MSMs sharded over %d GPUs by index range, all-gather of partial "
-                                       "points; H-scalar chain %s" % (world, "split (four-step NTTs, 2 all-to-alls per "
+                       "parallelism": ("one proof, five MSMs sharded over %d GPUs (sections 5-8 block-cyclic, blocks of 2^%d "
+                                       "items; H cyclic or by range), all-gather of partial points; H-scalar chain %s"
+                                       % (world, block_log, "split (four-step NTTs, 2 all-to-alls per "
                                        "proof, all three polynomials in each)" if split else "replicated")) if world > 1 else "single GPU",
                        "checked": checked},
             "roofline": roof,

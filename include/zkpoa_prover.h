@@ -105,7 +105,9 @@ int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_publi
  * lo = rank * (n / world) + min(rank, n % world), cnt = n / world + (rank < n % world); d_H that range of section 9,
  * or with split != 0 the cyclic shard H[t * world + rank], t < domain / world (copied: the handle owns its copy);
  * d_coef_records all n_coefs records, or with split != 0 at least those of the constraints c = rank (mod world)
- * (others are ignored). The handle is a shard: zkpoa_prove_partials (+ the split stages) and zkpoa_prove_assemble. */
+ * (others are ignored). The handle is a shard: zkpoa_prove_partials (+ the split stages) and zkpoa_prove_assemble.
+ * `split` is a set of shard flags (below): 1 = ZKPOA_SHARD_SPLIT_CHAIN as before; with ZKPOA_SHARD_BLOCK_CYCLIC(L)
+ * d_A, d_B1, d_B2, d_C hold this rank's blocks of 2^L items (block b = rank mod world), concatenated. */
 int zkpoa_zkey_load_device_shard(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
                                  uint64_t rank, uint64_t world, int split, const void* d_A, const void* d_B1,
                                  const void* d_B2, const void* d_C, const void* d_H, const void* d_coef_records,
@@ -126,6 +128,20 @@ int zkpoa_prove_device(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* d
  * RCCL has no elliptic-curve reduction operator, so "all-reduce of partial sums" = all-gather + local add. */
 int zkpoa_zkey_load_shard(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
                           uint64_t rank, uint64_t world, zkpoa_zkey** zkey);
+/* Shard flags (zkpoa_zkey_load_shard_ex, and the `split` argument of zkpoa_zkey_load_device_shard):
+ *   ZKPOA_SHARD_SPLIT_CHAIN      the H-scalar chain is split over the ranks too (what zkpoa_zkey_load_shard_split does);
+ *   ZKPOA_SHARD_BLOCK_CYCLIC(L)  sections 5-8 are dealt out in blocks of 2^L consecutive items (wires for A / B1 / B2,
+ *                                section indices for C), block b to rank b mod world, instead of one contiguous range
+ *                                per rank: real witnesses cluster (runs of bits, runs of full-width limbs), and equal
+ *                                index ranges are then unequal work. Every block is still one contiguous byte range of
+ *                                the file. L in 4..24; ZKPOA_SHARD_BLOCK_DEFAULT = blocks of 2^16.
+ * The multi-GPU path of groth16_prover_zkey_file (env ZKPOA_DEVICES) loads its shards with both. */
+#define ZKPOA_SHARD_SPLIT_CHAIN 0x1
+#define ZKPOA_SHARD_BLOCK_CYCLIC(L) (((L) & 0xff) << 8)
+#define ZKPOA_SHARD_BLOCK_LOG(flags) ((unsigned)(((flags) >> 8) & 0xff))
+#define ZKPOA_SHARD_BLOCK_DEFAULT ZKPOA_SHARD_BLOCK_CYCLIC(16)
+int zkpoa_zkey_load_shard_ex(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                             uint64_t rank, uint64_t world, int flags, zkpoa_zkey** zkey);
 int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t world);
 int zkpoa_zkey_header(const zkpoa_zkey* zkey, uint8_t header_points[448]);
 int zkpoa_prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zkey, const void* wtns_buffer, unsigned long wtns_size,

@@ -297,6 +297,69 @@ def test_prover_cli_drop_in(zk, tmp_path):
     assert (tmp_path / "public_s.json").read_text() == g["public_snarkjs.json"]
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0", "0,0,0,0,0,0,0,0"])
+@pytest.mark.parametrize("tag", ["n8", "n128"])
+def test_prover_cli_one_proof_over_several_ranks(zk, tmp_path, devices, tag):
+    """multi-GPU BEHIND the reference's boundary -- the unchanged argv of scripts/g16_prove.sh:248-252,
+    no Python. ZKPOA_DEVICES lists the HIP device of every rank; on this one-GPU box the ranks share device 0
+    (rehearsal): one process, one context + host thread per rank, shards loaded from the file's byte ranges
+    (block-cyclic sections 5-8, cyclic section 9), the split chain's two exchanges as device-to-device copies, partial
+    sums added on the host. 2 / 4 / 8 ranks split the chain where rank^2 <= domain (n8: domain 8 -> only 2 ranks do),
+    3 ranks replicate it. The bytes must be the golden ones."""
+    g = golden_case(tag)
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_DEVICES=devices, ZKPOA_VERBOSE="1")
+    env.pop("ZKPOA_SERVER", None)
+    rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"], env=env,
+                        capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert rc.returncode == 0, rc.stderr
+    n_ranks = devices.count(",") + 1
+    assert "one proof over %d ranks" % n_ranks in rc.stderr, rc.stderr
+    domain = 8 if tag == "n8" else 128
+    want_split = n_ranks in (2, 4, 8) and n_ranks * n_ranks <= domain
+    assert ("H-scalar chain split" in rc.stderr) == want_split, rc.stderr
+    assert "self-check: proof verifies" in rc.stderr
+    assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+    assert (tmp_path / "public.json").read_text() == g["public_rapidsnark.json"]
+
+
+def test_prover_cli_several_ranks_mid_size_server_and_errors(zk, tmp_path, mid_circuit):
+    """The same path at 2^13 with real block-cyclic shards (4 ranks, blocks of 2^7 wires), through the resident server:
+    first call loads the shards, the second builds every shard's fixed-base tables, the third is served from the cache
+    -- all three byte-identical to the single-device proof; then the error conventions (bad device list, short witness)."""
+    zkey, vk, wt, n_pub = mid_circuit
+    (tmp_path / "circuit_final.zkey").write_bytes(zkey)
+    (tmp_path / "witness.wtns").write_bytes(wt)
+    (tmp_path / "short.wtns").write_bytes(golden_case("n8")["witness.wtns"])
+    base = dict(os.environ, ZKPOA_R="12345678901234567890", ZKPOA_S="98765432109876543210", ZKPOA_VERBOSE="1")
+    base.pop("ZKPOA_SERVER", None)
+    argv = lambda out: [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", out + ".json", out + "_public.json"]
+    rc = subprocess.run(argv("single"), env=dict(base, ZKPOA_DEVICE="0"), capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert rc.returncode == 0, rc.stderr
+    want = (tmp_path / "single.json").read_text()
+    sock = str(tmp_path / "prover.sock")
+    env = dict(base, ZKPOA_DEVICES="0,0,0,0", ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60")
+    try:
+        for i in range(3):
+            rc = subprocess.run(argv("multi%d" % i), env=env, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+            assert rc.returncode == 0, rc.stderr
+            assert (tmp_path / ("multi%d.json" % i)).read_text() == want
+            assert (tmp_path / ("multi%d_public.json" % i)).read_text() == (tmp_path / "single_public.json").read_text()
+        log = (tmp_path / "prover.sock.log").read_text()
+        assert log.count("| zkey sharded load ") == 1 and log.count("| zkey cached,") == 2
+        assert "fixed-base tables for the cached key on 4 ranks" in log and "sections 5-8 block-cyclic" in log
+        rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "short.wtns", "bad.json", "bad_public.json"], env=env,
+                            capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert rc.returncode == 1 and "Invalid witness length" in rc.stderr and not (tmp_path / "bad.json").exists()
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+    for bad in ("0,x", "0,99", "0,,1", ",", "0,0,0,0,0,0,0,0,0"):
+        rc = subprocess.run(argv("bad"), env=dict(base, ZKPOA_DEVICES=bad), capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert rc.returncode != 0 and "ZKPOA_DEVICES" in rc.stderr and not (tmp_path / "bad.json").exists(), (bad, rc.stderr)
+
+
 def test_prover_cli_server_mode(zk, tmp_path):
     """ZKPOA_SERVER: same argv, exit codes and output bytes, but the proofs come from a resident prover
     process that keeps the key in HBM between calls (second call = cache hit)."""
@@ -595,6 +658,38 @@ def test_set_shard_split_on_resident_key(ctx, zk, log_domain, world):
         circ.close()
 
 
+@pytest.mark.parametrize("world,split,block_log", [(2, False, 6), (3, False, 4), (4, True, 7), (8, True, 5), (2, True, 13)])
+def test_block_cyclic_shards_from_file_equal_unsharded(ctx, zk, mid_circuit, world, split, block_log):
+    """zkpoa_zkey_load_shard_ex with ZKPOA_SHARD_BLOCK_CYCLIC(L): sections 5-8 dealt out in blocks of 2^L items (each
+    one byte range of the file), H cyclic (split) or by range; the partial sums assemble into the unsharded proof, bit
+    for bit, with and without the shards' fixed-base tables. (2^13 blocks of 7000 wires: rank 1 holds nothing.)"""
+    zkey, _, wt, _ = mid_circuit
+    rng = random.Random(31)
+    r_, s_ = rng.randrange(R), rng.randrange(R)
+    full = ctx.load_zkey(zkey)
+    try:
+        want, pub = ctx.prove(full, wt, r_, s_)
+        header = full.header()
+    finally:
+        full.close()
+    keys = [ctx.load_zkey_shard_ex(zkey, rank, world, split=split, block_log=block_log) for rank in range(world)]
+    try:
+        def partials():
+            if split:
+                for k in keys:
+                    ctx.witness_load(k, wt)
+                return _split_chain_partials(ctx, keys, world, 1 << 13)
+            return [ctx.prove_partials(k, wt)[0] for k in keys]
+        parts = partials()
+        assert zk.prove_assemble(header, zk.sum_partials(parts), r_, s_) == want
+        for k in keys:
+            k.precompute()
+        assert partials() == parts
+    finally:
+        for k in keys:
+            k.close()
+
+
 @pytest.mark.parametrize("log_domain,world,split", [(14, 2, False), (14, 3, False), (14, 4, True), (18, 8, True),
                                                      (16, 2, True)])
 def test_per_rank_generated_shards_equal_unsharded(ctx, zk, log_domain, world, split):
@@ -609,11 +704,13 @@ def test_per_rank_generated_shards_equal_unsharded(ctx, zk, log_domain, world, s
         header = whole.key.header()
     finally:
         whole.close()
-    ranks = [SyntheticCircuit(zk, ctx, log_domain, m, n_public=2, seed=9, witness_like=True, shard=(r, world, split))
-             for r in range(world)]
+    # every other case deals sections 5-8 out block-cyclically (bench.py --gpus N does), the rest by contiguous ranges
+    block_log = 9 if (log_domain + world) % 2 == 0 else 0
+    ranks = [SyntheticCircuit(zk, ctx, log_domain, m, n_public=2, seed=9, witness_like=True,
+                              shard=(r, world, split, block_log)) for r in range(world)]
     try:
-        # a shard holds 1/world of every point section
-        assert all(abs(c.d_A.numel() - whole.d_A.numel() // world) <= 64 for c in ranks)
+        # a shard holds 1/world of every point section (up to one block)
+        assert all(abs(c.d_A.numel() - whole.d_A.numel() // world) <= 64 * max(1, 1 << block_log) for c in ranks)
         assert all(c.key.header() == header for c in ranks)
         with pytest.raises(zk.ZkpoaError, match="shard"):
             ranks[0].prove(5, 7)

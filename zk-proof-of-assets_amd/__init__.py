@@ -31,7 +31,7 @@ EXPORTS = [
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
     "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute", "zkpoa_wtns_check",
-    "zkpoa_zkey_load_shard", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
+    "zkpoa_zkey_load_shard", "zkpoa_zkey_load_shard_ex", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
     "zkpoa_split_stage1", "zkpoa_split_stage2", "zkpoa_split_stage3",
@@ -53,6 +53,11 @@ EXPORTS = [
 
 class ZkpoaError(RuntimeError):
     pass
+
+
+def shard_flags(split=False, block_log=0):
+    """include/zkpoa_prover.h: ZKPOA_SHARD_SPLIT_CHAIN | ZKPOA_SHARD_BLOCK_CYCLIC(block_log)."""
+    return (1 if split else 0) | ((int(block_log) & 0xff) << 8)
 
 
 _lib = None
@@ -138,6 +143,8 @@ def lib():
             [ctypes.c_void_p] * 6 + [ctypes.c_uint64, ctypes.c_char_p, c_void_pp]
         L.zkpoa_prove_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p,
                                          ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong]
+        L.zkpoa_zkey_load_shard_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_uint64,
+                                               ctypes.c_uint64, ctypes.c_int, c_void_pp]
         L.zkpoa_zkey_load_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_uint64,
                                             ctypes.c_uint64, c_void_pp]
         L.zkpoa_zkey_set_shard.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
@@ -393,14 +400,15 @@ class Context:
                     "zkpoa_zkey_contribute")
 
     def load_zkey_device_shard(self, n_vars, n_public, log_domain, rank, world, split, d_A, d_B1, d_B2, d_C, d_H,
-                               d_coefs, n_coefs, header_points):
-        """Shard `rank` of `world` from device-resident sections that hold only this rank's ranges
-        (include/zkpoa_prover.h: zkpoa_zkey_load_device_shard); the caller keeps the buffers alive."""
+                               d_coefs, n_coefs, header_points, block_log=0):
+        """Shard `rank` of `world` from device-resident sections that hold only this rank's ranges -- or, with
+        block_log = L > 0, its blocks of 2^L items (block b to rank b mod world) concatenated
+        (include/zkpoa_prover.h: zkpoa_zkey_load_device_shard, ZKPOA_SHARD_*); the caller keeps the buffers alive."""
         key = ZKey.__new__(ZKey)
         key._ctx = self
         key._h = ctypes.c_void_p()
         self._check(lib().zkpoa_zkey_load_device_shard(self._h, n_vars, n_public, log_domain, rank, world,
-                                                       1 if split else 0, d_A, d_B1, d_B2, d_C, d_H, d_coefs, n_coefs,
+                                                       shard_flags(split, block_log), d_A, d_B1, d_B2, d_C, d_H, d_coefs, n_coefs,
                                                        bytes(header_points), ctypes.byref(key._h)),
                     "zkpoa_zkey_load_device_shard")
         return key
@@ -413,6 +421,18 @@ class Context:
         p, k = _buf(zkey_bytes)
         self._check(lib().zkpoa_zkey_load_shard(self._h, p, len(zkey_bytes), rank, world, ctypes.byref(key._h)),
                     "zkpoa_zkey_load_shard")
+        return key
+
+    def load_zkey_shard_ex(self, zkey_bytes, rank, world, split=False, block_log=0):
+        """Shard `rank` of `world` with shard flags (include/zkpoa_prover.h ZKPOA_SHARD_*): `split` = the H-scalar chain
+        is split too; block_log = L > 0 = sections 5-8 dealt out in blocks of 2^L items instead of one range per rank
+        (what the prover's own multi-GPU path, env ZKPOA_DEVICES, loads)."""
+        key = ZKey.__new__(ZKey)
+        key._ctx = self
+        key._h = ctypes.c_void_p()
+        p, k = _buf(zkey_bytes)
+        self._check(lib().zkpoa_zkey_load_shard_ex(self._h, p, len(zkey_bytes), rank, world, shard_flags(split, block_log),
+                                                   ctypes.byref(key._h)), "zkpoa_zkey_load_shard_ex")
         return key
 
     def load_zkey_shard_split(self, zkey_bytes, rank, world):

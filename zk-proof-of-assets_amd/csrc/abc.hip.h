@@ -242,10 +242,18 @@ static __global__ __launch_bounds__(256) void query_keep_kernel(const uint4* __r
   keep[i] = o ? 1u : 0u;
 }
 
-// pos = exclusive scan of keep: kept point i goes to slot pos[i]; wire[slot] = wire0 + i
+// Block-cyclic shards (prover.hip zkpoa_zkey::bc_log): local index j of a rank's concatenated blocks of 2^L items ->
+// global index; L == 0: contiguous range starting at base
+ZK_DEV uint32_t bc_global(uint32_t j, uint32_t base, uint32_t L, uint32_t rank, uint32_t world) {
+  if (L == 0) return base + j;
+  return (((j >> L) * world + rank) << L) + (j & ((1u << L) - 1u));
+}
+
+// pos = exclusive scan of keep: kept point i goes to slot pos[i]; wire[slot] = the wire of resident point i
 static __global__ __launch_bounds__(256) void query_compact_kernel(const uint4* __restrict__ g1, const uint4* __restrict__ g2,
                                                                    const uint32_t* __restrict__ pos, uint32_t n,
-                                                                   uint32_t wire0, uint4* __restrict__ c1,
+                                                                   uint32_t wire0, uint32_t bc_log, uint32_t bc_rank,
+                                                                   uint32_t bc_world, uint4* __restrict__ c1,
                                                                    uint4* __restrict__ c2, uint32_t* __restrict__ wire) {
   uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -257,7 +265,7 @@ static __global__ __launch_bounds__(256) void query_compact_kernel(const uint4* 
 #pragma unroll
     for (int k = 0; k < 8; k++) c2[(size_t)s * 8 + k] = g2[(size_t)i * 8 + k];
   }
-  wire[s] = wire0 + i;
+  wire[s] = bc_global(i, wire0, bc_log, bc_rank, bc_world);
 }
 
 // out[j] = values[idx[j]], 32-byte elements (two 16-byte quarters per thread pair)
@@ -266,6 +274,15 @@ static __global__ __launch_bounds__(256) void gather32_kernel(const uint4* __res
   uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (q >= count * 2u) return;
   out[q] = values[(uint64_t)idx[q >> 1] * 2u + (q & 1u)];
+}
+
+// out[j] = values[global(j)], 32-byte elements: the C query's witness values of a block-cyclic shard
+static __global__ __launch_bounds__(256) void gather_bc32_kernel(const uint4* __restrict__ values, uint64_t count,
+                                                                 uint32_t bc_log, uint32_t bc_rank, uint32_t bc_world,
+                                                                 uint4* __restrict__ out) {
+  uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (q >= count * 2u) return;
+  out[q] = values[(uint64_t)bc_global((uint32_t)(q >> 1), 0u, bc_log, bc_rank, bc_world) * 2u + (q & 1u)];
 }
 
 }  // namespace zkpoa

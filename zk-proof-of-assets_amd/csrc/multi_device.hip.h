@@ -1,0 +1,398 @@
+// One proof over several GPUs INSIDE the drop-in prover (BASELINE.json configs[3], [4]).
+//
+// The reference's boundary is one exec'd binary (scripts/g16_prove.sh:248-252) and, per batch, one such process
+// (scripts/full_workflow.sh:552). So the multi-GPU path lives behind that same entry point, in C++, with no Python and
+// no process group: ONE process, one zkpoa_context per device each driven by its own host thread ("rank"), the key
+// sharded straight from the file's byte ranges (zkey_load_impl: block-cyclic sections 5-8, cyclic section 9, the
+// coefficient rows c = rank mod G), the H-scalar chain split as in zkpoa_split_stage1/2/3 with its two all-to-all
+// exchanges done as peer-to-peer copies over xGMI (hipMemcpyPeerAsync: every rank pushes chunk h of its buffer to rank
+// h in a single hop, all links busy at once, no ring), and the five 64/128-byte partial results summed on the host.
+// Included by prover.hip inside its anonymous namespace.
+//
+// Which devices (env, read once per process):
+//   ZKPOA_DEVICES=0,1,2,3   exactly these HIP devices, one rank each (a device may be listed more than once: ranks
+//                           then share it -- how the path is rehearsed on a one-GPU box);
+//   ZKPOA_DEVICE=n          that one device (the single-GPU path, as before);
+//   neither                 automatic: each GPU has a lock file /tmp/zkpoa-<uid>/gpu<N>.lock held for the life of the
+//                           process that proves on it. A key whose domain is >= 2^ZKPOA_MULTI_MIN_POWER (default 24)
+//                           takes every GPU that is free (rounded down to a power of two), a smaller key one free GPU
+//                           -- so the reference's parallel batch jobs (full_workflow.sh:552) spread over the GPUs of the
+//                           node instead of all landing on GPU 0, and a layer-three proof run alone uses all of them.
+//                           When no GPU is free the process waits for GPU (pid mod count).
+#pragma once
+
+struct RankBarrier {   // host barrier of the rank threads (C++17: no std::barrier)
+  std::mutex m;
+  std::condition_variable cv;
+  unsigned n, waiting = 0, generation = 0;
+  explicit RankBarrier(unsigned count) : n(count) {}
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned gen = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != generation; });
+    }
+  }
+};
+
+struct DeviceSet {
+  std::vector<int> ids;                // HIP device of every rank
+  std::vector<zkpoa_context*> ctx;     // one context per rank (ranks that share a device have their own streams)
+  std::vector<int> lock_fds;           // automatic selection: the GPUs' lock files, held until the process ends
+  bool automatic = false;
+};
+
+std::mutex g_devset_mutex;
+DeviceSet* g_devset = nullptr;
+
+bool devices_ready() {
+  std::lock_guard<std::mutex> lk(g_devset_mutex);
+  return g_devset != nullptr;
+}
+
+std::string gpu_lock_dir() { return "/tmp/zkpoa-" + std::to_string((long)getuid()); }
+
+int try_lock_gpu(int dev, bool block) {
+  const std::string dir = gpu_lock_dir();
+  (void)mkdir(dir.c_str(), 0700);
+  const std::string path = dir + "/gpu" + std::to_string(dev) + ".lock";
+  int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+  if (fd < 0) return -1;
+  if (flock(fd, LOCK_EX | (block ? 0 : LOCK_NB)) != 0) {
+    close(fd);
+    return -1;
+  }
+  const std::string pid = std::to_string((long)getpid()) + "\n";
+  if (ftruncate(fd, 0) == 0) (void)!pwrite(fd, pid.data(), pid.size(), 0);
+  return fd;
+}
+
+// the device list for this process; `power` = log2 of the first key's domain (automatic selection only)
+void select_devices(DeviceSet& ds, uint32_t power) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw HipError("zkpoa: no HIP device visible (the MSM/NTT path is HIP-only; there is no CPU fallback)");
+  if (const char* e = getenv("ZKPOA_DEVICES")) {
+    if (*e && strcmp(e, "auto") != 0) {
+      for (const char* p = e; *p;) {
+        char* end = nullptr;
+        long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || v >= count)
+          throw ProverError(PROVER_ERROR, std::string("ZKPOA_DEVICES: '") + e + "' is not a comma-separated list of device "
+                                          "indices below " + std::to_string(count));
+        ds.ids.push_back((int)v);
+        p = end;
+        if (*p == ',') p++;
+        else if (*p) throw ProverError(PROVER_ERROR, std::string("ZKPOA_DEVICES: unexpected character in '") + e + "'");
+      }
+      if (ds.ids.empty() || ds.ids.size() > 8) throw ProverError(PROVER_ERROR, "ZKPOA_DEVICES: between 1 and 8 devices");
+      return;
+    }
+  }
+  if (const char* e = getenv("ZKPOA_DEVICE")) {
+    if (*e) {
+      ds.ids.push_back(atoi(e));
+      return;
+    }
+  }
+  if (count == 1) {
+    ds.ids.push_back(0);
+    return;
+  }
+  ds.automatic = true;
+  uint32_t min_power = 24;
+  if (const char* e = getenv("ZKPOA_MULTI_MIN_POWER")) min_power = (uint32_t)atoi(e);
+  const int want = power >= min_power ? (count > 8 ? 8 : count) : 1;
+  const int first = want == 1 ? (int)((unsigned long)getpid() % (unsigned long)count) : 0;   // batch jobs start at different GPUs
+  for (int k = 0; k < count && (int)ds.ids.size() < want; k++) {
+    const int d = (first + k) % count;
+    int fd = try_lock_gpu(d, false);
+    if (fd >= 0) {
+      ds.ids.push_back(d);
+      ds.lock_fds.push_back(fd);
+    }
+  }
+  if (ds.ids.empty()) {   // every GPU is taken: queue behind one of them
+    const int d = (int)((unsigned long)getpid() % (unsigned long)count);
+    int fd = try_lock_gpu(d, true);
+    ds.ids.push_back(d);
+    if (fd >= 0) ds.lock_fds.push_back(fd);
+  }
+  size_t keep = 1;
+  while (keep * 2 <= ds.ids.size()) keep *= 2;   // the split chain wants 2, 4 or 8 ranks
+  while (ds.ids.size() > keep) {
+    ds.ids.pop_back();
+    close(ds.lock_fds.back());
+    ds.lock_fds.pop_back();
+  }
+}
+
+// Contexts of the process, created once (first prove decides the device list). Ranks come up in parallel: a context
+// costs 60-200 ms (HIP runtime, first stream).
+DeviceSet* process_devices(uint32_t power, std::string& err) {
+  std::lock_guard<std::mutex> lk(g_devset_mutex);
+  if (g_devset) return g_devset;
+  std::unique_ptr<DeviceSet> ds(new DeviceSet());
+  try {
+    auto t0 = std::chrono::steady_clock::now();
+    select_devices(*ds, power);
+    const size_t G = ds->ids.size();
+    ds->ctx.assign(G, nullptr);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++)
+      th.emplace_back([&, g] {
+        char msg[512] = {0};
+        if (zkpoa_context_create(ds->ids[g], &ds->ctx[g], msg, sizeof(msg)) != PROVER_OK) errs[g] = msg[0] ? msg : "context creation failed";
+      });
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+      if (!errs[g].empty()) {
+        for (auto* c : ds->ctx)
+          if (c) zkpoa_context_destroy(c);
+        throw HipError(errs[g]);
+      }
+    // peer access between distinct devices: the exchanges then go GPU to GPU over xGMI instead of through the host
+    for (size_t g = 0; g < G; g++)
+      for (size_t h = 0; h < G; h++) {
+        if (ds->ids[g] == ds->ids[h]) continue;
+        int can = 0;
+        ZK_HIP(hipSetDevice(ds->ids[g]));
+        if (hipDeviceCanAccessPeer(&can, ds->ids[g], ds->ids[h]) == hipSuccess && can) {
+          hipError_t pe = hipDeviceEnablePeerAccess(ds->ids[h], 0);
+          if (pe != hipSuccess) (void)hipGetLastError();   // already enabled (devices listed twice), or not: copies still work
+        }
+      }
+    if (getenv("ZKPOA_VERBOSE")) {
+      std::string list;
+      for (size_t g = 0; g < G; g++) list += (g ? "," : "") + std::to_string(ds->ids[g]);
+      fprintf(stderr, "zkpoa: %zu rank(s) on HIP device(s) %s%s, contexts ready in %.1f ms\n", G, list.c_str(),
+              ds->automatic ? " (picked by lock file)" : "",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+  } catch (const std::exception& e) {
+    err = e.what();
+    return nullptr;
+  }
+  g_devset = ds.release();
+  g_ctx = g_devset->ctx[0];
+  return g_devset;
+}
+
+// ---- a key sharded over the ranks of the process ----------------------------------------------------------------------
+struct MultiKey {
+  std::vector<zkpoa_zkey*> shards;          // shard g lives on context g
+  bool split = false;                       // H-scalar chain split (G in {2, 4, 8}, G^2 <= domain) or replicated
+  std::vector<void*> xa, xb1, xb2;          // per rank: send buffer, receive buffers of the two exchanges
+  std::vector<hipEvent_t> ev1, ev2;         // per rank: "my pushes of exchange 1 / 2 are enqueued up to here"
+  uint64_t xbytes = 0;                      // bytes of one exchange buffer: 3 * (domain / G) * 32
+  uint64_t proofs_done = 0, table_bytes = 0;
+  double load_ms = 0;
+};
+
+void multi_key_release(DeviceSet* ds, MultiKey* mk) {
+  if (!mk) return;
+  for (size_t g = 0; g < mk->shards.size(); g++) {
+    (void)hipSetDevice(ds->ids[g]);
+    (void)hipDeviceSynchronize();
+    for (std::vector<void*>* v : {&mk->xa, &mk->xb1, &mk->xb2})
+      if (g < v->size() && (*v)[g]) (void)hipFree((*v)[g]);
+    if (g < mk->ev1.size() && mk->ev1[g]) (void)hipEventDestroy(mk->ev1[g]);
+    if (g < mk->ev2.size() && mk->ev2[g]) (void)hipEventDestroy(mk->ev2[g]);
+    if (mk->shards[g]) {
+      mk->shards[g]->release();
+      delete mk->shards[g];
+    }
+  }
+  delete mk;
+}
+
+// run fn(g) on one thread per rank; the first exception (by rank) is rethrown after all have joined
+template <class Fn>
+void for_each_rank(DeviceSet* ds, Fn fn) {
+  const size_t G = ds->ids.size();
+  std::vector<std::exception_ptr> errs(G);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; g++)
+    th.emplace_back([&, g] {
+      try {
+        ZK_HIP(hipSetDevice(ds->ids[g]));
+        fn(g);
+      } catch (...) {
+        errs[g] = std::current_exception();
+      }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+// Block size of the block-cyclic sections: 2^16 items, less for small keys so that every rank still gets at least
+// eight blocks (and the test-size keys exercise the same path). ZKPOA_SHARD_BLOCK_LOG overrides; 0 = contiguous ranges.
+uint32_t multi_block_log(uint64_t n_vars, size_t G) {
+  if (const char* e = getenv("ZKPOA_SHARD_BLOCK_LOG")) return (uint32_t)atoi(e);
+  uint32_t L = 16;
+  while (L > 4 && (n_vars >> L) < 8 * (uint64_t)G) L--;
+  return L;
+}
+
+MultiKey* multi_key_load(DeviceSet* ds, const uint8_t* buf, uint64_t size) {
+  const size_t G = ds->ids.size();
+  std::unique_ptr<MultiKey> mk(new MultiKey());
+  mk->shards.assign(G, nullptr);
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    ZkeySections zs;
+    std::unique_ptr<zkpoa_zkey> hdr = zkey_parse(buf, size, zs);   // validates the container once, before G uploads start
+    mk->split = (G == 2 || G == 4 || G == 8) && (uint64_t)hdr->domain >= (uint64_t)G * G;
+    const uint32_t bc = multi_block_log(hdr->nVars, G);
+    for_each_rank(ds, [&](size_t g) { mk->shards[g] = zkey_load_impl(ds->ctx[g], buf, size, g, G, mk->split, bc); });
+    if (mk->split) {
+      mk->xbytes = (uint64_t)3 * (hdr->domain / G) * 32;
+      mk->xa.assign(G, nullptr);
+      mk->xb1.assign(G, nullptr);
+      mk->xb2.assign(G, nullptr);
+      mk->ev1.assign(G, nullptr);
+      mk->ev2.assign(G, nullptr);
+      for (size_t g = 0; g < G; g++) {
+        ZK_HIP(hipSetDevice(ds->ids[g]));
+        ZK_HIP(hipMalloc(&mk->xa[g], mk->xbytes));
+        ZK_HIP(hipMalloc(&mk->xb1[g], mk->xbytes));
+        ZK_HIP(hipMalloc(&mk->xb2[g], mk->xbytes));
+        ZK_HIP(hipEventCreateWithFlags(&mk->ev1[g], hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&mk->ev2[g], hipEventDisableTiming));
+      }
+    }
+  } catch (...) {
+    multi_key_release(ds, mk.release());
+    throw;
+  }
+  mk->load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return mk.release();
+}
+
+// One exchange of the split chain, rank g's half: push chunk h of `src` (what rank h needs from g) into slot g of rank
+// h's receive buffer, all on g's lane-0 stream behind the stage that produced `src`; then mark the stream.
+void multi_push(DeviceSet* ds, MultiKey* mk, size_t g, const void* src, std::vector<void*>& dst, hipEvent_t done) {
+  const size_t G = ds->ids.size();
+  const uint64_t chunk = mk->xbytes / G;
+  hipStream_t st = ds->ctx[g]->dev.lanes[0].stream;
+  for (size_t k = 0; k < G; k++) {
+    const size_t h = (g + k) % G;   // start with the own slot, then round the ring: no two ranks aim at one peer at once
+    const char* s = reinterpret_cast<const char*>(src) + h * chunk;
+    char* d = reinterpret_cast<char*>(dst[h]) + g * chunk;
+    if (ds->ids[g] == ds->ids[h]) ZK_HIP(hipMemcpyAsync(d, s, chunk, hipMemcpyDeviceToDevice, st));
+    else ZK_HIP(hipMemcpyPeerAsync(d, ds->ids[h], s, ds->ids[g], chunk, st));
+  }
+  ZK_HIP(hipEventRecord(done, st));
+}
+
+// The proof's five partial sums over all ranks: parts_sum = A(64) B1(64) B2(128) C(64) H(64).
+void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_t parts_sum[384]) {
+  const size_t G = ds->ids.size();
+  std::vector<std::array<uint8_t, 384>> parts(G);
+  RankBarrier bar((unsigned)G);
+  std::atomic<bool> failed{false};
+  std::vector<std::exception_ptr> errs(G);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; g++)
+    th.emplace_back([&, g] {
+      // Phases separated by barriers; a rank that fails keeps arriving at the barriers so that nobody waits for ever.
+      auto phase = [&](const std::function<void()>& fn) {
+        if (failed.load()) return;
+        try {
+          fn();
+        } catch (...) {
+          errs[g] = std::current_exception();
+          failed.store(true);
+        }
+      };
+      zkpoa_context* ctx = ds->ctx[g];
+      zkpoa_zkey* zk = mk->shards[g];
+      hipStream_t st = nullptr;
+      phase([&] {
+        ZK_HIP(hipSetDevice(ds->ids[g]));
+        st = ctx->dev.lanes[0].stream;
+        ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, st);   // replicated
+        zk->h_ready = false;
+        if (mk->split) {
+          split_stage1(ctx, zk, mk->xa[g]);
+          multi_push(ds, mk, g, mk->xa[g], mk->xb1, mk->ev1[g]);
+        }
+      });
+      if (mk->split) {
+        bar.arrive_and_wait();   // every rank's event has been recorded: waiting on an unrecorded event is a no-op
+        phase([&] {
+          for (size_t h = 0; h < G; h++) ZK_HIP(hipStreamWaitEvent(st, mk->ev1[h], 0));
+          split_stage2(ctx, zk, mk->xb1[g], mk->xa[g]);   // xa[g] is free: this stream's own pushes precede this stage
+          multi_push(ds, mk, g, mk->xa[g], mk->xb2, mk->ev2[g]);
+        });
+        bar.arrive_and_wait();
+        phase([&] {
+          for (size_t h = 0; h < G; h++) ZK_HIP(hipStreamWaitEvent(st, mk->ev2[h], 0));
+          split_stage3(ctx, zk, mk->xb2[g]);
+        });
+      }
+      // the witness MSMs start at once on their own lanes and overlap the chain still in flight on lane 0
+      phase([&] { prove_partials(ctx, zk, parts[g].data()); });
+      // a rank must not start the next proof's pushes into a peer that still reads this proof's buffers
+      phase([&] { ZK_HIP(hipStreamSynchronize(st)); });
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+  // "all-reduce of the partial sums": five tiny host-side group sums (G points each)
+  const struct { size_t off, len; bool g2; } kParts[5] = {{0, 64, false}, {64, 64, false}, {128, 128, true}, {256, 64, false}, {320, 64, false}};
+  for (const auto& p : kParts) {
+    std::vector<uint8_t> col(G * p.len);
+    for (size_t g = 0; g < G; g++) memcpy(&col[g * p.len], parts[g].data() + p.off, p.len);
+    int rc = p.g2 ? zkpoa_g2_sum(col.data(), G, parts_sum + p.off) : zkpoa_g1_sum(col.data(), G, parts_sum + p.off);
+    if (rc != PROVER_OK) throw ProverError(PROVER_ERROR, "multi-GPU prove: a partial result is not a curve point");
+  }
+}
+
+// fixed-base tables of every shard (1 / G of the memory per GPU: on 8 GPUs all five sections of a 2^26 key fit)
+void multi_precompute(DeviceSet* ds, MultiKey* mk) {
+  std::vector<uint64_t> used(ds->ids.size(), 0);
+  for_each_rank(ds, [&](size_t g) {
+    try {
+      used[g] = zkey_precompute(ds->ctx[g], mk->shards[g], 0);
+    } catch (const HipError&) {   // out of HBM: the classic form keeps working
+      mk->shards[g]->release_tables();
+      (void)hipGetLastError();
+    }
+  });
+  mk->table_bytes = 0;
+  for (uint64_t u : used) mk->table_bytes += u;
+}
+
+// witness -> proof JSON on a loaded MultiKey (the multi-GPU twin of prove_to_json)
+int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+                        unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
+                        unsigned long error_msg_maxsize, uint64_t zkey_size, bool cache_hit) {
+  zkpoa_zkey* z0 = mk->shards[0];
+  zkpoa_context* c0 = ds->ctx[0];
+  WtnsView w = parse_wtns(wtns, wtns_size);
+  if (w.n != z0->nVars)
+    throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(z0->nVars) +
+                                                         ", witness: " + std::to_string(w.n));
+  uint8_t rb[32], sb[32], parts[384], header[448], pts[256];
+  const uint8_t *rp = nullptr, *sp = nullptr;
+  env_blinding(rb, sb, rp, sp);
+  auto t0 = std::chrono::steady_clock::now();
+  multi_prove_partials(ds, mk, w, parts);
+  zkey_header_bytes(z0, header);
+  prove_assemble(header, parts, rp, sp, pts);
+  c0->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  selfcheck(c0, z0, pts, w.values + 32);
+  if (getenv("ZKPOA_VERBOSE"))
+    fprintf(stderr, "zkpoa: one proof over %zu ranks: H-scalar chain %s, sections 5-8 %s, %.2f GB of fixed-base tables; "
+                    "prove %.2f ms\n", ds->ids.size(), mk->split ? "split (2 peer-to-peer exchanges)" : "replicated",
+            z0->bc_log ? "block-cyclic" : "contiguous ranges", mk->table_bytes / 1e9, c0->ms[5]);
+  return emit_outputs(c0, z0, pts, w.values + 32, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                      error_msg_maxsize, mk->load_ms, zkey_size, cache_hit ? "cached," : "sharded load");
+}

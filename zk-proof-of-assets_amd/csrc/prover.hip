@@ -12,12 +12,15 @@
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
 #include <functional>
 #include <future>
@@ -138,6 +141,21 @@ struct zkpoa_zkey {
   void* dHs = nullptr;           // cyclic H shard (owned), domain / split_world points
   mutable bool h_ready = false;  // d_abc[0 .. domain/split_world) holds this proof's H scalars (stage 3 done)
   uint64_t nCoefsLocal = 0;
+  // Block-cyclic shard of sections 5-8 (bc_log > 0; shard handles only): this rank holds the blocks b = bc_rank
+  // (mod bc_world) of 2^bc_log consecutive items -- wires for A / B1 / B2, section indices for C -- concatenated. A
+  // contiguous range inherits whatever clustering a real witness has (bit-decomposition wires come in runs of cheap
+  // 0 / 1 scalars, limbs in runs of full-width ones), so ranks would finish at different times; blocks of 2^16 wires
+  // dealt round-robin even that out while every block is still one contiguous byte range of the file. Local index j
+  // of a section <-> global index (((j >> L) * world + rank) << L) + (j & (2^L - 1)).
+  uint32_t bc_log = 0, bc_rank = 0, bc_world = 1;
+  void* d_cscal = nullptr;       // block-cyclic handles: the C query's witness values, gathered per proof
+  static uint64_t bc_count(uint64_t n, uint32_t L, uint64_t rank, uint64_t world) {
+    const uint64_t B = 1ull << L, nb = (n + B - 1) >> L;
+    if (nb <= rank) return 0;
+    uint64_t cnt = ((nb - rank + world - 1) / world) << L;
+    if ((nb - 1) % world == rank && (n & (B - 1))) cnt -= B - (n & (B - 1));
+    return cnt;
+  }
   // A and B queries without their points at infinity (abc.hip.h): compacted copies of the resident range of
   // section 5 resp. 6 / 7, the wire of every kept point, pos[i] = kept points before resident wire i (a shard's
   // slice of the compacted arrays is [pos[wlo - wbase], pos[wlo + wcnt - wbase])), and the gathered scalars.
@@ -194,12 +212,12 @@ struct zkpoa_zkey {
     if (owns_points)
       for (void* p : pts)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long, d_flag};
+    void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long, d_flag, d_cscal};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     qA.release();
     qB.release();
-    dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = nullptr;
+    dA = dB1 = dB2 = dC = dH = d_vals = d_abc = d_witness = dHs = d_cscal = nullptr;
     d_long = nullptr;
     d_flag = nullptr;
     d_row_ptr = d_sig = nullptr;
@@ -338,7 +356,8 @@ void query_compact(zkpoa_context* ctx, zkpoa_zkey* zk, zkpoa_zkey::CompactQuery&
   ZK_HIP(hipMalloc(reinterpret_cast<void**>(&q.wire), cnt * 4));
   if (n) {
     hipLaunchKernelGGL(query_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)d1, (const uint4*)d2,
-                       (const uint32_t*)q.pos, n, (uint32_t)zk->wbase, (uint4*)q.g1, (uint4*)q.g2, q.wire);
+                       (const uint32_t*)q.pos, n, (uint32_t)zk->wbase, zk->bc_log, zk->bc_rank, zk->bc_world, (uint4*)q.g1,
+                       (uint4*)q.g2, q.wire);
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
   }
@@ -425,13 +444,25 @@ std::unique_ptr<zkpoa_zkey> zkey_parse(const uint8_t* buf, uint64_t size, ZkeySe
   return zk;
 }
 
+// shard flags of the loaders (include/zkpoa_prover.h ZKPOA_SHARD_*): bit 0 = split chain, bits 8-15 = block-cyclic log
+void set_block_cyclic(zkpoa_zkey* zk, uint64_t rank, uint64_t world, uint32_t bc_log) {
+  if (bc_log == 0 || world <= 1) return;
+  if (bc_log < 4 || bc_log > 24) throw ProverError(PROVER_ERROR, "zkey shard: block-cyclic block size must be 2^4 .. 2^24 items");
+  zk->bc_log = bc_log;
+  zk->bc_rank = (uint32_t)rank;
+  zk->bc_world = (uint32_t)world;
+  zk->wlo = zk->wbase = 0;
+  zk->wcnt = zkpoa_zkey::bc_count(zk->nVars, bc_log, rank, world);
+  zk->clo = zk->cbase = 0;
+  zk->ccnt = zkpoa_zkey::bc_count((uint64_t)zk->nVars - zk->nPublic - 1, bc_log, rank, world);
+}
+
 zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size, uint64_t rank = 0,
-                           uint64_t world = 1, bool split = false) {
+                           uint64_t world = 1, bool split = false, uint32_t bc_log = 0) {
   ZkeySections zs;
   std::unique_ptr<zkpoa_zkey> zk = zkey_parse(buf, size, zs);
   const Section &s4 = zs.s4, &s5 = zs.s5, &s6 = zs.s6, &s7 = zs.s7, &s8 = zs.s8, &s9 = zs.s9;
   const uint64_t m = zk->nVars, n = zk->domain;
-  (void)m;
 
   if (world == 0 || rank >= world) throw ProverError(PROVER_ERROR, "zkey shard: rank/world out of range");
   zk->set_shard(rank, world);   // world == 1: the whole key
@@ -442,6 +473,7 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     check_split(zk.get(), rank, world);
     set_split(zk.get(), rank, world);
   }
+  set_block_cyclic(zk.get(), rank, world, bc_log);
   const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
   auto tph = std::chrono::steady_clock::now();
   auto phase = [&](const char* what) {   // ZKPOA_VERBOSE: where a key load spends its time
@@ -452,11 +484,32 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     tph = now;
   };
   try {
-    // each rank uploads only its byte range of every point section
-    zk->dA = dev_upload(ctx, s5.p + zk->wlo * 64, zk->wcnt * 64);
-    zk->dB1 = dev_upload(ctx, s6.p + zk->wlo * 64, zk->wcnt * 64);
-    zk->dB2 = dev_upload(ctx, s7.p + zk->wlo * 128, zk->wcnt * 128);
-    zk->dC = dev_upload(ctx, s8.p + zk->clo * 64, zk->ccnt * 64);
+    // each rank uploads only its byte range(s) of every point section: one contiguous range, or with block-cyclic
+    // shards its blocks of 2^bc_log items one after the other (each still a contiguous byte range of the file)
+    auto upload_items = [&](const uint8_t* sec, uint64_t n_items, uint64_t lo, uint64_t cnt, size_t unit) -> void* {
+      if (!zk->bc_log) return dev_upload(ctx, sec + lo * unit, cnt * unit);
+      void* d = nullptr;
+      ZK_HIP(hipMalloc(&d, cnt ? cnt * unit : 1));
+      try {
+        const uint64_t B = 1ull << zk->bc_log;
+        for (uint64_t lb = 0;; lb++) {
+          const uint64_t start = (lb * world + rank) << zk->bc_log;
+          if (start >= n_items) break;
+          const uint64_t len = n_items - start < B ? n_items - start : B;
+          ctx->uploader.upload(reinterpret_cast<char*>(d) + (lb << zk->bc_log) * unit, sec + start * unit, len * unit,
+                               ctx->dev.device, ctx->dev.lanes[0].stream);
+        }
+      } catch (...) {
+        (void)hipFree(d);
+        throw;
+      }
+      return d;
+    };
+    zk->dA = upload_items(s5.p, m, zk->wlo, zk->wcnt, 64);
+    zk->dB1 = upload_items(s6.p, m, zk->wlo, zk->wcnt, 64);
+    zk->dB2 = upload_items(s7.p, m, zk->wlo, zk->wcnt, 128);
+    zk->dC = upload_items(s8.p, m - zk->nPublic - 1, zk->clo, zk->ccnt, 64);
+    if (zk->bc_log) ZK_HIP(hipMalloc(&zk->d_cscal, zk->ccnt ? zk->ccnt * 32 : 1));
     if (split) {
       // cyclic H shard: H[t * world + rank], gathered on the host (the section is walked once per rank)
       const uint64_t cnt = n / world;
@@ -848,6 +901,14 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     const char* pC = reinterpret_cast<const char*>(zk->dC) + (zk->clo - zk->cbase) * 64;
     const char* witC = reinterpret_cast<const char*>(zk->d_witness) + ((uint64_t)zk->nPublic + 1 + zk->clo) * 32;
     if (!zk->d_witness || (zk->ccnt && !zk->dC)) throw ProverError(PROVER_ERROR, "internal: C stage started before its inputs");
+    if (zk->bc_log) {   // block-cyclic shard: the scalars of this rank's blocks, gathered in the order of its points
+      if (zk->ccnt)
+        hipLaunchKernelGGL(gather_bc32_kernel, dim3((uint32_t)((zk->ccnt * 2 + 255) / 256)), dim3(256), 0,
+                           ctx->dev.lanes[4].stream,
+                           reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(zk->d_witness) + ((uint64_t)zk->nPublic + 1) * 32),
+                           zk->ccnt, zk->bc_log, zk->bc_rank, zk->bc_world, (uint4*)zk->d_cscal);
+      witC = reinterpret_cast<const char*>(zk->d_cscal);
+    }
     msm_set_density_hint(with_density(4));
     msm_run_g1(ctx, 4, pC, witC, zk->ccnt, outC, msm_ms[4], useC);
   });
@@ -1268,22 +1329,8 @@ std::mutex g_ctx_mutex;
 zkpoa_context* g_ctx = nullptr;
 std::mutex g_prove_mutex;   // one-shot entry points share the process-wide context: one proof at a time
 
-zkpoa_context* process_context(std::string& err) {
-  std::lock_guard<std::mutex> lk(g_ctx_mutex);
-  if (g_ctx) return g_ctx;
-  int dev = 0;
-  if (const char* e = getenv("ZKPOA_DEVICE")) dev = atoi(e);
-  char msg[512] = {0};
-  auto t0 = std::chrono::steady_clock::now();
-  if (zkpoa_context_create(dev, &g_ctx, msg, sizeof(msg)) != PROVER_OK) {
-    err = msg;
-    g_ctx = nullptr;
-  } else if (getenv("ZKPOA_VERBOSE")) {
-    fprintf(stderr, "zkpoa: HIP runtime + context ready in %.1f ms\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-  }
-  return g_ctx;
-}
+struct DeviceSet;
+DeviceSet* process_devices(uint32_t power, std::string& err);   // multi_device.hip.h: the device list of this process
 
 // r, s from the environment (ZKPOA_R / ZKPOA_S, decimal; test use) -> pointers, or null for /dev/urandom
 void env_blinding(uint8_t rb[32], uint8_t sb[32], const uint8_t*& rp, const uint8_t*& sp) {
@@ -1378,22 +1425,44 @@ int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zke
                        error_msg_maxsize, load_ms, zkey_size, false);
 }
 
+#include "multi_device.hip.h"
+
+// log2(domain) of a zkey image, for the automatic device selection (throws what zkey_parse throws)
+uint32_t zkey_power(const uint8_t* buf, uint64_t size) {
+  ZkeySections zs;
+  return zkey_parse(buf, size, zs)->power;
+}
+
 int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
              unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
              unsigned long error_msg_maxsize) {
   std::string err;
-  zkpoa_context* ctx = process_context(err);
-  if (!ctx) {
+  DeviceSet* ds = nullptr;
+  try {
+    ds = process_devices(zkey_power(zkey, zkey_size), err);
+  } catch (const std::exception& e) {   // malformed key: nothing touches a GPU
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+  if (!ds) {
     set_err(error_msg, error_msg_maxsize, err);
     return PROVER_ERROR;
   }
+  zkpoa_context* ctx = ds->ctx[0];
   std::lock_guard<std::mutex> lk(g_prove_mutex);
   zkpoa_zkey* zk = nullptr;
+  MultiKey* mk = nullptr;
   int rc = PROVER_OK;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
-    rc = load_and_prove_to_json(ctx, zkey, zkey_size, wtns, wtns_size, proof_buffer, proof_size, public_buffer,
-                                public_size, error_msg, error_msg_maxsize, &zk);
+    if (ds->ids.size() > 1) {   // one proof over all ranks of the process
+      mk = multi_key_load(ds, zkey, zkey_size);
+      rc = multi_prove_to_json(ds, mk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                               error_msg_maxsize, zkey_size, false);
+    } else {
+      rc = load_and_prove_to_json(ctx, zkey, zkey_size, wtns, wtns_size, proof_buffer, proof_size, public_buffer,
+                                  public_size, error_msg, error_msg_maxsize, &zk);
+    }
   } catch (const ProverError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = e.code;
@@ -1414,6 +1483,7 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
     zk->release();
     delete zk;
   }
+  if (mk) multi_key_release(ds, mk);
   return rc;
 }
 
@@ -1453,6 +1523,102 @@ void key_cache_clear() {
   while (!g_key_cache.empty()) key_cache_drop(g_key_cache.size() - 1);
 }
 
+// The same cache for keys sharded over the ranks of a multi-GPU process (one entry = G shard handles + their exchange
+// buffers); the second use of a key builds every shard's fixed-base tables, in parallel on the G devices.
+struct CachedMultiKey {
+  dev_t dev;
+  ino_t ino;
+  off_t size;
+  struct timespec mtime;
+  MultiKey* mk;
+  uint64_t last_use;
+};
+std::vector<CachedMultiKey> g_multi_cache;
+
+int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* path, const uint8_t* wtns, uint64_t wtns_size,
+                     char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
+                     char* error_msg, unsigned long error_msg_maxsize) {
+  int rc = PROVER_OK;
+  MultiKey* mk = nullptr;
+  bool cached = false, hit = false;
+  try {
+    const size_t cap = key_cache_capacity();
+    for (auto& c : g_multi_cache)
+      if (c.dev == sb.st_dev && c.ino == sb.st_ino && c.size == sb.st_size && c.mtime.tv_sec == sb.st_mtim.tv_sec &&
+          c.mtime.tv_nsec == sb.st_mtim.tv_nsec) {
+        mk = c.mk;
+        c.last_use = ++g_key_clock;
+        hit = cached = true;
+      }
+    auto drop = [&](size_t idx) {
+      multi_key_release(ds, g_multi_cache[idx].mk);
+      g_multi_cache.erase(g_multi_cache.begin() + (long)idx);
+    };
+    if (!mk) {
+      void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (map == MAP_FAILED) throw ProverError(PROVER_ERROR, std::string("cannot mmap zkey file ") + path);
+      try {
+        while (cap && g_multi_cache.size() >= cap) {
+          size_t lru = 0;
+          for (size_t i = 1; i < g_multi_cache.size(); i++)
+            if (g_multi_cache[i].last_use < g_multi_cache[lru].last_use) lru = i;
+          drop(lru);
+        }
+        try {
+          mk = multi_key_load(ds, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+        } catch (const HipError&) {
+          if (g_multi_cache.empty()) throw;
+          while (!g_multi_cache.empty()) drop(g_multi_cache.size() - 1);   // probably out of HBM: retry alone
+          for (int d : ds->ids) {
+            (void)hipSetDevice(d);
+            (void)hipGetLastError();
+          }
+          mk = multi_key_load(ds, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+        }
+      } catch (...) {
+        munmap(map, (size_t)sb.st_size);
+        throw;
+      }
+      munmap(map, (size_t)sb.st_size);
+      if (cap) {
+        g_multi_cache.push_back({sb.st_dev, sb.st_ino, sb.st_size, sb.st_mtim, mk, ++g_key_clock});
+        cached = true;
+      }
+    }
+    if (hit && mk->proofs_done == 1 && mk->table_bytes == 0) {
+      const char* e = getenv("ZKPOA_PRECOMP");
+      if (!e || strcmp(e, "0") != 0) {
+        auto tp0 = std::chrono::steady_clock::now();
+        multi_precompute(ds, mk);
+        if (getenv("ZKPOA_VERBOSE"))
+          fprintf(stderr, "zkpoa: fixed-base tables for the cached key on %zu ranks: %.2f GB in %.0f ms\n", ds->ids.size(),
+                  mk->table_bytes / 1e9,
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+      }
+    }
+    rc = multi_prove_to_json(ds, mk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                             error_msg_maxsize, (uint64_t)sb.st_size, hit);
+    mk->proofs_done++;
+  } catch (const ProverError& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = e.code;
+  } catch (const HipError& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::bad_alloc&) {
+    set_err(error_msg, error_msg_maxsize, "out of host memory");
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::system_error& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR_RUNTIME;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    rc = PROVER_ERROR;
+  }
+  if (mk && !cached) multi_key_release(ds, mk);
+  return rc;
+}
+
 int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
                     unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
                     unsigned long error_msg_maxsize) {
@@ -1468,13 +1634,39 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
     return PROVER_ERROR;
   }
   std::string err;
-  zkpoa_context* ctx = process_context(err);
-  if (!ctx) {
+  DeviceSet* ds = nullptr;
+  try {
+    uint32_t power = 0;
+    if (!devices_ready()) {   // the first key of the process decides the device list: its domain size is in the header
+      void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (map == MAP_FAILED) throw ProverError(PROVER_ERROR, std::string("cannot mmap zkey file ") + path);
+      try {
+        power = zkey_power(reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size);
+      } catch (...) {
+        munmap(map, (size_t)sb.st_size);
+        throw;
+      }
+      munmap(map, (size_t)sb.st_size);
+    }
+    ds = process_devices(power, err);
+  } catch (const std::exception& e) {   // malformed key: nothing touches a GPU
+    close(fd);
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+  if (!ds) {
     close(fd);
     set_err(error_msg, error_msg_maxsize, err);
     return PROVER_ERROR;
   }
+  zkpoa_context* ctx = ds->ctx[0];
   std::lock_guard<std::mutex> lk(g_prove_mutex);
+  if (ds->ids.size() > 1) {
+    int rc = multi_file_prove(ds, fd, sb, path, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+                              error_msg, error_msg_maxsize);
+    close(fd);
+    return rc;
+  }
   int rc = PROVER_OK;
   zkpoa_zkey* zk = nullptr;
   bool owned = false, hit = false, proved = false;
@@ -1611,7 +1803,7 @@ extern "C" int zkpoa_zkey_load_shard(zkpoa_context* ctx, const void* zkey_buffer
 
 extern "C" int zkpoa_zkey_set_shard(zkpoa_zkey* zkey, uint64_t rank, uint64_t world) {
   if (!zkey || world == 0 || rank >= world) return PROVER_ERROR;
-  if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH)
+  if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH || zkey->bc_log)
     return PROVER_ERROR;  // only a fully resident key can be re-sharded
   zkey->set_shard(rank, world);
   zkey->split_world = zkey->split_rank = zkey->split_log = 0;
@@ -1636,11 +1828,24 @@ extern "C" int zkpoa_zkey_load_shard_split(zkpoa_context* ctx, const void* zkey_
   return PROVER_OK;
 }
 
+extern "C" int zkpoa_zkey_load_shard_ex(zkpoa_context* ctx, const void* zkey_buffer, unsigned long zkey_size,
+                                        uint64_t rank, uint64_t world, int flags, zkpoa_zkey** out) {
+  if (!ctx || !out || !zkey_buffer) return PROVER_ERROR;
+  *out = nullptr;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    *out = zkey_load_impl(ctx, reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size, rank, world,
+                          (flags & ZKPOA_SHARD_SPLIT_CHAIN) != 0, ZKPOA_SHARD_BLOCK_LOG(flags));
+  }
+  ZK_PROVER_CATCH(ctx)
+  return PROVER_OK;
+}
+
 extern "C" int zkpoa_zkey_set_shard_split(zkpoa_context* ctx, zkpoa_zkey* zkey, uint64_t rank, uint64_t world) {
   if (!ctx || !zkey) return PROVER_ERROR;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
-    if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH)
+    if (zkey->wbase || zkey->cbase || zkey->hbase || zkey->csr_local || !zkey->dH || zkey->bc_log)
       throw ProverError(PROVER_ERROR, "only a fully resident key can be re-sharded");
     check_split(zkey, rank, world);
     hipStream_t st = ctx->dev.lanes[0].stream;
@@ -1846,7 +2051,7 @@ extern "C" int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey, const voi
 // `split`, d_H is the cyclic shard H[t * world + rank] and the records are those of the constraints
 // c = rank (mod world) (records of other constraints are ignored).
 static zkpoa_zkey* zkey_load_device_impl(zkpoa_context* ctx, uint64_t n_vars, uint64_t n_public, unsigned log_domain,
-                                         uint64_t rank, uint64_t world, bool split, const void* d_A, const void* d_B1,
+                                         uint64_t rank, uint64_t world, bool split, uint32_t bc_log, const void* d_A, const void* d_B1,
                                          const void* d_B2, const void* d_C, const void* d_H,
                                          const void* d_coef_records, uint64_t n_coefs, const uint8_t header_points[448]) {
   std::unique_ptr<zkpoa_zkey> zk(new zkpoa_zkey());
@@ -1886,6 +2091,8 @@ static zkpoa_zkey* zkey_load_device_impl(zkpoa_context* ctx, uint64_t n_vars, ui
     } else {
       zk->dH = const_cast<void*>(d_H);
     }
+    set_block_cyclic(zk.get(), rank, world, bc_log);
+    if (zk->bc_log) ZK_HIP(hipMalloc(&zk->d_cscal, zk->ccnt ? zk->ccnt * 32 : 1));
     queries_compact(ctx, zk.get(), zk->wcnt);
     build_csr(ctx, zk.get(), d_coef_records, split);
     ntt_prepare(ctx, ctx->dev.lanes[0].stream, zk->power);
@@ -1906,7 +2113,7 @@ extern "C" int zkpoa_zkey_load_device(zkpoa_context* ctx, uint64_t n_vars, uint6
   *out = nullptr;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
-    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, 0, 1, false, d_A, d_B1, d_B2, d_C, d_H,
+    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, 0, 1, false, 0, d_A, d_B1, d_B2, d_C, d_H,
                                  d_coef_records, n_coefs, header_points);
   }
   ZK_PROVER_CATCH(ctx)
@@ -1922,7 +2129,8 @@ extern "C" int zkpoa_zkey_load_device_shard(zkpoa_context* ctx, uint64_t n_vars,
   *out = nullptr;
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
-    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, rank, world, split != 0, d_A, d_B1, d_B2, d_C, d_H,
+    *out = zkey_load_device_impl(ctx, n_vars, n_public, log_domain, rank, world, (split & ZKPOA_SHARD_SPLIT_CHAIN) != 0,
+                                 ZKPOA_SHARD_BLOCK_LOG(split), d_A, d_B1, d_B2, d_C, d_H,
                                  d_coef_records, n_coefs, header_points);
   }
   ZK_PROVER_CATCH(ctx)

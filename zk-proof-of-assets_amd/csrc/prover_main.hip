@@ -122,6 +122,7 @@ static int prove_files(const char* zkey, const char* wtns_path, const char* proo
 // server failed -- it reported a HIP runtime failure, died, or did not answer -- one line goes to a persistent log
 // /tmp/zkpoa-<uid>/faults.log (time, pid, what happened, the key) and its path to stderr. ZKPOA_STRICT=1 turns the
 // fallback into a non-zero exit instead (the workflow's ERR trap fires and somebody looks at the machine).
+static std::string abs_path(const char* p);
 static std::string fault_log_path() {
   return "/tmp/zkpoa-" + std::to_string((long)getuid()) + "/faults.log";
 }
@@ -135,7 +136,7 @@ static void log_fault(const char* what, const std::string& detail, const char* z
   gmtime_r(&now, &tmv);
   strftime(when, sizeof(when), "%Y-%m-%dT%H:%M:%SZ", &tmv);
   std::string line = std::string(when) + " pid " + std::to_string((long)getpid()) + " " + what + ": " + detail +
-                     " | zkey " + (zkey ? zkey : "-") + "\n";
+                     " | zkey " + (zkey ? abs_path(zkey) : std::string("-")) + "\n";
   for (char& c : line)
     if ((c == '\n' || c == '\r') && &c != &line[line.size() - 1]) c = ' ';
   int fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND | O_CLOEXEC, 0600);

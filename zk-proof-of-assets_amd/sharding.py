@@ -24,6 +24,15 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def block_cyclic_blocks(n, rank, world, block_log):
+    """The (global start, count) runs of n items that `rank` holds when blocks of 2^block_log consecutive items are
+    dealt round-robin (block b to rank b mod world) -- include/zkpoa_prover.h ZKPOA_SHARD_BLOCK_CYCLIC. Contiguous
+    ranges inherit the clustering of a real witness (runs of bits, runs of full-width limbs: equal ranges, unequal
+    work); small blocks even that out and each is still one contiguous byte range of the zkey file."""
+    B = 1 << block_log
+    return [(s, min(B, n - s)) for s in range(rank * B, n, world * B)]
+
+
 def all_gather_bytes(payload, dist=None, device=None):
     """All-gather a fixed-size byte string over the default process group; returns the list by rank.
     On RCCL the ranks' payloads land in ONE tensor and come back with one device-to-host copy (the payload is a

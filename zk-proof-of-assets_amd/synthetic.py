@@ -68,13 +68,14 @@ class SyntheticCircuit:
 
     def __init__(self, zk, ctx, log_domain, n_vars, n_public=1, seed=0x5EED0010, witness_like=False, device=None,
                  shard=None):
-        """shard = (rank, world, split): generate and keep only that rank's part of the key -- its index ranges of
-        the point sections (sharding.shard_range), with `split` the cyclic H shard and the coefficient records of its
+        """shard = (rank, world, split[, block_log]): generate and keep only that rank's part of the key -- its index
+        ranges of the point sections (sharding.shard_range) or, with block_log = L > 0, its blocks of 2^L items dealt
+        round-robin (sharding.block_cyclic_indices), with `split` the cyclic H shard and the coefficient records of its
         own constraints -- and load it with zkpoa_zkey_load_device_shard. Same key as the unsharded circuit of the
         same seed, so the N partial results add up to its proof. The witness is whole on every rank."""
         import numpy as np
         import torch
-        from .sharding import shard_range
+        from .sharding import block_cyclic_blocks, shard_range
         self.zk, self.ctx = zk, ctx
         self.k, self.n, self.m, self.n_public = log_domain, 1 << log_domain, n_vars, n_public
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -83,18 +84,29 @@ class SyntheticCircuit:
         self.hdr = {x: rng.randrange(1, 1 << 64) for x in ("alpha", "beta", "delta")}
         m, n = self.m, self.n
         nC = m - n_public - 1
-        rank, world, split = shard if shard is not None else (0, 1, False)
+        rank, world, split = (tuple(shard) + (0,))[:3] if shard is not None else (0, 1, False)
+        block_log = shard[3] if shard is not None and len(shard) > 3 and world > 1 else 0
         self.shard = (rank, world, bool(split)) if shard is not None else None
+        self.block_log = block_log
         (wlo, whi), (clo, chi), (hlo, hhi) = (shard_range(x, rank, world) for x in (m, nC, n))
-        wcnt, ccnt, hcnt = whi - wlo, chi - clo, hhi - hlo
+        # the pieces of sections 5-8 this rank holds, as (global start, count) runs: one range, or its blocks
+        wruns = block_cyclic_blocks(m, rank, world, block_log) if block_log else [(wlo, whi - wlo)]
+        cruns = block_cyclic_blocks(nC, rank, world, block_log) if block_log else [(clo, chi - clo)]
+        wcnt, ccnt, hcnt = sum(c for _, c in wruns), sum(c for _, c in cruns), hhi - hlo
         self.d_A = torch.empty(max(wcnt, 1) * 64, dtype=torch.uint8, device=dev)
         self.d_B1 = torch.empty(max(wcnt, 1) * 64, dtype=torch.uint8, device=dev)
         self.d_B2 = torch.empty(max(wcnt, 1) * 128, dtype=torch.uint8, device=dev)
         self.d_C = torch.empty(max(ccnt, 1) * 64, dtype=torch.uint8, device=dev)
-        ctx.gen_bases_g1_device(*self.par["A"], wlo, wcnt, self.d_A.data_ptr())
-        ctx.gen_bases_g1_device(*self.par["B"], wlo, wcnt, self.d_B1.data_ptr())
-        ctx.gen_bases_g2_device(*self.par["B"], wlo, wcnt, self.d_B2.data_ptr())
-        ctx.gen_bases_g1_device(*self.par["C"], clo, ccnt, self.d_C.data_ptr())
+        at = 0
+        for start, cnt in wruns:
+            ctx.gen_bases_g1_device(*self.par["A"], start, cnt, self.d_A.data_ptr() + at * 64)
+            ctx.gen_bases_g1_device(*self.par["B"], start, cnt, self.d_B1.data_ptr() + at * 64)
+            ctx.gen_bases_g2_device(*self.par["B"], start, cnt, self.d_B2.data_ptr() + at * 128)
+            at += cnt
+        at = 0
+        for start, cnt in cruns:
+            ctx.gen_bases_g1_device(*self.par["C"], start, cnt, self.d_C.data_ptr() + at * 64)
+            at += cnt
         if split:
             # H[t * world + rank] = (a + rank * b + t * (world * b)) G: the same generator with shifted parameters
             ha, hb = self.par["H"]
@@ -150,9 +162,11 @@ class SyntheticCircuit:
         in_b[sig[:, 2].long()] = True
         self.in_a, self.in_b = in_a.numpy(), in_b.numpy()
         if wcnt:
-            self.d_A[:wcnt * 64].view(wcnt, 64)[(~in_a[wlo:wlo + wcnt]).to(dev)] = 0
-            self.d_B1[:wcnt * 64].view(wcnt, 64)[(~in_b[wlo:wlo + wcnt]).to(dev)] = 0
-            self.d_B2[:wcnt * 128].view(wcnt, 128)[(~in_b[wlo:wlo + wcnt]).to(dev)] = 0
+            mine_a = torch.cat([in_a[s0:s0 + c] for s0, c in wruns])      # presence flags in the order of this rank's points
+            mine_b = torch.cat([in_b[s0:s0 + c] for s0, c in wruns])
+            self.d_A[:wcnt * 64].view(wcnt, 64)[(~mine_a).to(dev)] = 0
+            self.d_B1[:wcnt * 64].view(wcnt, 64)[(~mine_b).to(dev)] = 0
+            self.d_B2[:wcnt * 128].view(wcnt, 128)[(~mine_b).to(dev)] = 0
         self.n_coef = n_coef
         self.recs_host = recs                              # [n_coef, 11] int32 == 44-byte records
         if split and not own_only:                         # only the records of this rank's constraints go to HBM
@@ -184,7 +198,8 @@ class SyntheticCircuit:
         else:
             self.key = ctx.load_zkey_device_shard(m, n_public, log_domain, rank, world, split, self.d_A.data_ptr(),
                                                   self.d_B1.data_ptr(), self.d_B2.data_ptr(), self.d_C.data_ptr(),
-                                                  self.d_H.data_ptr(), self.d_recs.data_ptr(), n_dev, hp)
+                                                  self.d_H.data_ptr(), self.d_recs.data_ptr(), n_dev, hp,
+                                                  block_log=block_log)
         self.header_points = hp
         self._G1, self._G2 = G1, G2
 
