@@ -83,6 +83,34 @@ __global__ __launch_bounds__(256) void k_modmul(const uint4* in, uint4* out, int
   store_field(out + 2 * t, s);
 }
 
+// r03: dedicated squaring (36 + 72 products) against a * a (64 + 72), and the Fq2 product (lazy dot2 form)
+template <int SQR>
+__global__ __launch_bounds__(256) void k_modsqr(const uint4* in, uint4* out, int iters) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  Fq x = load_field<Fq>(in + 2 * (t & 1023)), y = load_field<Fq>(in + 2 * ((t + 1) & 1023));
+  for (int i = 0; i < iters; i++) {
+    x = SQR ? x.sqr() : x * x;
+    y = SQR ? y.sqr() : y * y;
+  }
+  store_field(out + 2 * t, x + y);
+}
+__global__ __launch_bounds__(256) void k_fq2mul(const uint4* in, uint4* out, int iters) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  Fq2 x = {load_field<Fq>(in + 2 * (t & 1023)), load_field<Fq>(in + 2 * ((t + 1) & 1023))};
+  Fq2 y = {load_field<Fq>(in + 2 * ((t + 2) & 1023)), load_field<Fq>(in + 2 * ((t + 3) & 1023))};
+  for (int i = 0; i < iters; i++) x = x * y;
+  store_field(out + 2 * t, x.c0 + x.c1);
+}
+__global__ __launch_bounds__(256) void k_madd2(const uint4* in, uint4* out, int iters) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  auto ld = [&](int o) { return Fq2{load_field<Fq>(in + 2 * ((t + o) & 1023)), load_field<Fq>(in + 2 * ((t + o + 1) & 1023))}; };
+  Affine<Fq2> p = {ld(0), ld(2)};
+  XYZZ<Fq2> acc = {ld(4), ld(6), ld(8), ld(10)};
+  for (int i = 0; i < iters; i++) xyzz_add_affine(acc, p, false);
+  Fq2 s = acc.x + acc.y + acc.zz + acc.zzz;
+  store_field(out + 2 * t, s.c0 + s.c1);
+}
+
 __global__ __launch_bounds__(256) void k_madd(const uint4* in, uint4* out, int iters) {
   int t = blockIdx.x * 256 + threadIdx.x;
   Affine<Fq> p = {load_field<Fq>(in + 2 * (t & 1023)), load_field<Fq>(in + 2 * ((t + 7) & 1023))};
@@ -139,6 +167,20 @@ int main() {
     int grid = cus * wps, iters = 128;
     float ms = timeit(k_madd, grid, (const uint4*)din, dout, iters);
     printf("xyzz_add_affine wps=%d: %.3f ms  %.2f G adds/s\n", wps, ms, (double)grid * 256 * iters / ms / 1e6);
+  }
+  for (int wps : {2, 4, 8}) {
+    int grid = cus * wps, iters = 512;
+    float m0 = timeit(k_modsqr<0>, grid, (const uint4*)din, dout, iters);
+    float m1 = timeit(k_modsqr<1>, grid, (const uint4*)din, dout, iters);
+    printf("a*a vs sqr() wps=%d: %.3f / %.3f ms  %.1f / %.1f G per s\n", wps, m0, m1, (double)grid * 256 * iters * 2 / m0 / 1e6,
+           (double)grid * 256 * iters * 2 / m1 / 1e6);
+    float m2 = timeit(k_fq2mul, grid, (const uint4*)din, dout, iters);
+    printf("Fq2 mul (dot2) wps=%d: %.3f ms  %.1f G Fq2 products/s\n", wps, m2, (double)grid * 256 * iters / m2 / 1e6);
+  }
+  for (int wps : {1, 2}) {
+    int grid = cus * wps, iters = 64;
+    float ms = timeit(k_madd2, grid, (const uint4*)din, dout, iters);
+    printf("G2 xyzz_add_affine wps=%d: %.3f ms  %.2f G adds/s\n", wps, ms, (double)grid * 256 * iters / ms / 1e6);
   }
   return 0;
 }

@@ -71,6 +71,10 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   // space the GPU driver watches (measured: 11 % of the six-in-flight 2^20 MSM rate)
   std::vector<char> host_sums;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // scratch of the single-launch scans (msm.hip.h scan_pair): status words + ticket counters, cleared only when
+  // (re)allocated -- every call stamps its words with the next generation number
+  void* scan_scratch = nullptr;
+  uint32_t scan_tiles = 0, scan_gen = 0;
   // level 2 = highest, 1 = middle, 0 = lowest stream priority
   void init(int level = 0) {
     int lo = 0, hi = 0;  // numerically lower = higher priority
@@ -87,6 +91,9 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   }
   void destroy() {
     ws.release();
+    if (scan_scratch) (void)hipFree(scan_scratch);
+    scan_scratch = nullptr;
+    scan_tiles = scan_gen = 0;
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
     if (ev0) (void)hipEventDestroy(ev0);

@@ -304,6 +304,189 @@ inline void scan_u32(hipStream_t st, const uint32_t* in, uint32_t n, int mode, u
                      out);
 }
 
+// ---- 2b: the same scans in ONE launch (decoupled look-back), two at a time ------------------------------------
+// The MSM's hot path runs its scans in pairs over one input (bucket counts -> entry offsets and piece offsets; segment
+// counts -> entry offsets and task offsets) and each scan_u32 is three launches: 12 of the ~45 launches of a 2^20 MSM,
+// every one a few microseconds of kernel plus a dependency bubble on a lane whose proof is latency-shaped (VERDICT r02:
+// 2205 launches of scan_reduce / spine / apply in a 26-proof profile). scan_pair_kernel does both scans (and the
+// optional maximum) in a single pass: a workgroup takes the next tile from a ticket counter (tiles start in index
+// order, so a tile never waits for one that has not been scheduled), publishes its aggregates, and a whole wavefront
+// looks back over the published prefixes of its predecessors, 64 tiles per step. Status words carry the call's
+// generation number, so the scratch is never cleared between calls; the last workgroup to finish rewinds the tickets.
+struct ScanPair {
+  const uint32_t* in;
+  uint32_t n;
+  int mode_a;
+  uint32_t K_a;
+  uint32_t* out_a;      // n + 1 entries
+  uint32_t* total_a;    // optional
+  int mode_b;           // < 0: no second scan
+  uint32_t K_b;
+  uint32_t* out_b;
+  uint32_t* total_b;
+  uint32_t* max_out;    // optional: atomicMax of the raw inputs
+};
+
+ZK_DEV uint64_t scan_status_load(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ZK_DEV void scan_status_store(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive prefix of tile `tile` for one of the two scans, by the first wavefront of the workgroup: publishes the
+// tile's aggregate, walks back 64 predecessors at a time until one with an inclusive prefix is met, then publishes
+// its own inclusive prefix. status: [ntiles] words of (generation << 2 | state) << 32 | value; state 1 = aggregate,
+// 2 = inclusive prefix.
+ZK_DEV uint32_t scan_look_back(uint64_t* status, uint32_t tile, uint32_t aggregate, uint32_t gen) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t tag1 = ((uint64_t)((gen << 2) | 1u)) << 32, tag2 = ((uint64_t)((gen << 2) | 2u)) << 32;
+  if (tile == 0) {
+    if (lane == 0) scan_status_store(&status[0], tag2 | aggregate);
+    return 0;
+  }
+  if (lane == 0) scan_status_store(&status[tile], tag1 | aggregate);
+  uint32_t running = 0;
+  int64_t top = (int64_t)tile - 1;   // highest tile not yet folded in
+  for (;;) {
+    const int64_t t = top - (int64_t)lane;
+    uint64_t w = 0;
+    uint32_t state = 2, val = 0;     // lanes before tile 0: an inclusive prefix of nothing
+    if (t >= 0) {
+      do {
+        w = scan_status_load(&status[t]);
+      } while ((uint32_t)(w >> 34) != gen || (((uint32_t)(w >> 32)) & 3u) == 0);
+      state = ((uint32_t)(w >> 32)) & 3u;
+      val = (uint32_t)w;
+    }
+    const uint64_t incl = __ballot(state == 2);          // non-zero: lanes below tile 0 count too
+    const uint32_t stop = incl ? (uint32_t)__builtin_ctzll(incl) : 63u;   // nearest predecessor that knows its whole prefix
+    uint32_t x = lane <= stop ? val : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    running += x;
+    if (incl) break;
+    top -= 64;
+  }
+  if (lane == 0) scan_status_store(&status[tile], tag2 | (running + aggregate));
+  return running;
+}
+
+static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a, uint64_t* __restrict__ status_a,
+                                                                      uint64_t* __restrict__ status_b,
+                                                                      uint32_t* __restrict__ tickets, uint32_t gen,
+                                                                      uint32_t ntiles) {
+  __shared__ uint32_t lds[8];
+  __shared__ uint32_t s_tile, s_pre_a, s_pre_b;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[0], 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
+  const bool two = a.mode_b >= 0;
+  uint32_t va[kScanItems], vb[kScanItems];
+  uint32_t sum_a = 0, sum_b = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    uint32_t raw;
+    va[k] = scan_input(a.in, base + k, a.n, a.mode_a, a.K_a, raw);
+    sum_a += va[k];
+    mx = raw > mx ? raw : mx;
+    vb[k] = 0;
+    if (two) {
+      if (a.mode_b == 0) vb[k] = raw;
+      else if (a.mode_b == 3 && raw <= 1) vb[k] = 0;
+      else vb[k] = (raw + a.K_b - 1) / a.K_b;
+      sum_b += vb[k];
+    }
+  }
+  uint32_t tot_a, tot_b = 0;
+  uint32_t ex_a = block_exclusive_scan(sum_a, lds, tot_a);
+  uint32_t ex_b = two ? block_exclusive_scan(sum_b, lds, tot_b) : 0;
+  if (threadIdx.x < 64) {
+    uint32_t pa = scan_look_back(status_a, tile, tot_a, gen);
+    uint32_t pb = two ? scan_look_back(status_b, tile, tot_b, gen) : 0;
+    if (threadIdx.x == 0) {
+      s_pre_a = pa;
+      s_pre_b = pb;
+    }
+  }
+  __syncthreads();
+  ex_a += s_pre_a;
+  ex_b += s_pre_b;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t idx = base + k;
+    if (idx < a.n) {
+      a.out_a[idx] = ex_a;
+      if (two) a.out_b[idx] = ex_b;
+    }
+    ex_a += va[k];
+    ex_b += vb[k];
+  }
+  if (tile == ntiles - 1 && threadIdx.x == kScanBlock - 1) {   // the last thread of the last tile holds the totals
+    a.out_a[a.n] = ex_a;
+    if (a.total_a) *a.total_a = ex_a;
+    if (two) {
+      a.out_b[a.n] = ex_b;
+      if (a.total_b) *a.total_b = ex_b;
+    }
+  }
+  if (a.max_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      uint32_t y = __shfl_xor(mx, o);
+      mx = y > mx ? y : mx;
+    }
+    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(a.max_out, mx);
+  }
+  // rewind the tickets for the next call (stream order: it cannot start before this grid has drained)
+  if (threadIdx.x == 0 && atomicAdd(&tickets[1], 1u) == ntiles - 1) {
+    tickets[0] = 0;
+    tickets[1] = 0;
+  }
+}
+
+inline bool scan_three_kernel() {
+  static const bool v = [] {
+    const char* e = getenv("ZKPOA_SCAN");
+    return e && !strcmp(e, "3");
+  }();
+  return v;
+}
+
+// Per-lane scratch of scan_pair (device_ctx.hpp Lane::scan_*): two status arrays + the ticket counters, zeroed when
+// (re)allocated only; gen counts the calls on the lane.
+inline void scan_pair(Lane& lane, const ScanPair& a) {
+  const uint32_t ntiles = (a.n + kScanTile - 1) / kScanTile;
+  if (ntiles == 0) {   // n == 0: the n + 1 outputs are the empty sums
+    ZK_HIP(hipMemsetAsync(a.out_a, 0, 4, lane.stream));
+    if (a.total_a) ZK_HIP(hipMemsetAsync(a.total_a, 0, 4, lane.stream));
+    if (a.mode_b >= 0) {
+      ZK_HIP(hipMemsetAsync(a.out_b, 0, 4, lane.stream));
+      if (a.total_b) ZK_HIP(hipMemsetAsync(a.total_b, 0, 4, lane.stream));
+    }
+    return;
+  }
+  if (lane.scan_tiles < ntiles || lane.scan_gen >= 0x3ffffff0u) {
+    ZK_HIP(hipStreamSynchronize(lane.stream));
+    if (lane.scan_scratch) ZK_HIP(hipFree(lane.scan_scratch));
+    lane.scan_scratch = nullptr;
+    const uint32_t cap = ntiles < 1024 ? 1024 : ntiles * 2;
+    const size_t bytes = (size_t)cap * 16 + 256;
+    ZK_HIP(hipMalloc(&lane.scan_scratch, bytes));
+    // on the lane's own stream: a null-stream hipMemset is not ordered against a non-blocking stream, and a clear that
+    // lands after the first scan has started would wipe live tickets and status words
+    ZK_HIP(hipMemsetAsync(lane.scan_scratch, 0, bytes, lane.stream));
+    lane.scan_tiles = cap;
+    lane.scan_gen = 0;
+  }
+  const uint32_t gen = ++lane.scan_gen;   // generation 0 never appears in a live status word
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(lane.scan_scratch);
+  uint64_t* st_a = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(lane.scan_scratch) + 256);
+  uint64_t* st_b = st_a + lane.scan_tiles;
+  hipLaunchKernelGGL(scan_pair_kernel, dim3(ntiles), dim3(kScanBlock), 0, lane.stream, a, st_a, st_b, tickets, gen, ntiles);
+}
+
 // ---- 4: accumulate --------------------------------------------------------------------------
 // largest b in [0, nb) with po[b] <= t  (po has nb+1 entries, non-decreasing, po[nb] > t)
 ZK_DEV uint32_t find_bucket(const uint32_t* __restrict__ po, uint32_t nb, uint32_t t) {
@@ -740,12 +923,19 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
         hipLaunchKernelGGL((msm_sort_count_kernel<false>), grid, dim3(256), 0, st, sp, l, (const uint32_t*)digits, in,
                            in_off, tpo, out_cnt, base[l]);
     }
-    if (last) {
-      scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
-      scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
-    } else {
-      scan_u32(st, seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], block_sums, misc + 4 + 2 * l, nullptr);
-      scan_u32(st, seg_cnt[l], sp.segs[l + 1], 1, sp.CH, seg_tpo[l], block_sums, misc + 5 + 2 * l, nullptr);
+    if (scan_three_kernel()) {   // ZKPOA_SCAN=3: the three-launch scans (A/B measurement)
+      if (last) {
+        scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
+        scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
+      } else {
+        scan_u32(st, seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], block_sums, misc + 4 + 2 * l, nullptr);
+        scan_u32(st, seg_cnt[l], sp.segs[l + 1], 1, sp.CH, seg_tpo[l], block_sums, misc + 5 + 2 * l, nullptr);
+      }
+    } else if (last) {   // bucket counts -> entry offsets + piece offsets (+ the largest bucket), one launch
+      scan_pair(lane, ScanPair{sr.counts, p.TB, 0, 0, sr.off0, misc + 0, 1, p.K0, sr.po_a, misc + 2, misc + 1});
+    } else {             // segment counts -> entry offsets + task offsets
+      scan_pair(lane, ScanPair{seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], misc + 4 + 2 * l, 1, sp.CH, seg_tpo[l],
+                               misc + 5 + 2 * l, nullptr});
     }
     if (p.n) {
 #define ZK_SORT_SCATTER(F_, L_)                                                                                       \
@@ -828,7 +1018,8 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   while (max_items > 1) {
     uint64_t bound = total_in / 2 + 1;  // every unfinished bucket holds >= 2 items and emits <= items/2 + 1 pieces
     if (bound > cap_out) throw HipError("msm: level buffer too small");
-    scan_u32(st, po_in, p.TB, 3, p.K, po_out, block_sums, misc + 3, nullptr);
+    if (scan_three_kernel()) scan_u32(st, po_in, p.TB, 3, p.K, po_out, block_sums, misc + 3, nullptr);
+    else scan_pair(lane, ScanPair{po_in, p.TB, 3, p.K, po_out, misc + 3, -1, 0, nullptr, nullptr, nullptr});
     hipLaunchKernelGGL((msm_accumN_kernel<F>), dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, st, (const void*)Pin,
                        po_in, (const uint32_t*)po_out, p.TB, p.K, (void*)buckets, (void*)Pout);
     max_items = (max_items + p.K - 1) / p.K;

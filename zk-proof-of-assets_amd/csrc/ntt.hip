@@ -9,8 +9,8 @@ static NttEngine* engine(zkpoa_context* ctx) {
   return ctx->ntt;
 }
 
-void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k) {
-  engine(ctx)->to_odd_coset(st, d_data, k);
+void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, uint32_t batch, size_t stride) {
+  engine(ctx)->to_odd_coset(st, d_data, k, batch, stride);
 }
 void ntt_natural(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
   engine(ctx)->transform_natural(st, d_data, k, inverse);
@@ -24,11 +24,11 @@ void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k) {
   HFr ninv = HFr::from_u64(1ull << k).inv();
   (void)e->pow_tables(st, k, inc, ninv, k);
 }
-void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
-  engine(ctx)->dif(st, d_data, k, inverse);
+void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse, uint32_t batch, size_t stride) {
+  engine(ctx)->dif(st, d_data, k, inverse, batch, stride);
 }
-void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse) {
-  engine(ctx)->dit(st, d_data, k, inverse);
+void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse, uint32_t batch, size_t stride) {
+  engine(ctx)->dit(st, d_data, k, inverse, batch, stride);
 }
 void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h,
                    uint32_t rank_stride) {

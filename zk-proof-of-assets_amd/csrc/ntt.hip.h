@@ -56,16 +56,19 @@ ZK_DEV Fr tw_lookup(const void* __restrict__ hi, const void* __restrict__ lo, ui
   return a * b;
 }
 
-ZK_DEV Fr lds_load(const uint4* lds, uint32_t idx) {
-  uint4 a = lds[2 * idx], b = lds[2 * idx + 1];
+// The tile lives in LDS as two planes of 16-byte halves (low limbs of every element, then high limbs): consecutive
+// lanes then touch consecutive 16-byte words. With the halves interleaved (32-byte stride) lanes i and i + 8 of a
+// ds_read_b128 group fall on the same banks: a two-way conflict on every access of every stage.
+ZK_DEV Fr lds_load(const uint4* lds, uint32_t plane, uint32_t idx) {
+  uint4 a = lds[idx], b = lds[plane + idx];
   Fr r;
   r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
   r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
   return r;
 }
-ZK_DEV void lds_store(uint4* lds, uint32_t idx, const Fr& v) {
-  lds[2 * idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-  lds[2 * idx + 1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+ZK_DEV void lds_store(uint4* lds, uint32_t plane, uint32_t idx, const Fr& v) {
+  lds[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  lds[plane + idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
 // What a pass folds into its load / store besides the butterflies (each saves a whole 64 B/element round trip):
@@ -89,8 +92,14 @@ static __global__ __launch_bounds__(256) void ntt_direct_table_kernel(void* __re
 // One pass over stages [s_lo, s_lo + B). Tile: 2^B rows (stride 2^s_lo elements) x 2^logT columns
 // (consecutive elements); requires logT <= s_lo. grid.x = n / 2^(B+logT). tw_direct (optional): the boundary
 // twiddles of this pass as one table (a single multiplication per element instead of hi * lo and then the product).
-template <bool DIF, int MODE>
-static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void* src, void* dst, uint32_t k, uint32_t s_lo,
+// blockIdx.y = which of `batch` equally sized vectors, `batch_stride` bytes apart (the prover transforms A, B and C
+// of a proof together: a third of the launches, three times the workgroups per launch, one set of twiddle tables).
+// R4: two butterfly stages per barrier -- every thread takes the four rows of a radix-4 group through both stages in
+// registers (half the LDS round trips and barriers; the multiplication count is unchanged: in a prime field the
+// "free" rotation by i of a complex radix-4 butterfly is an ordinary product).
+template <bool DIF, int MODE, bool R4>
+static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void* src, void* dst, size_t batch_stride,
+                                                              uint32_t k, uint32_t s_lo,
                                                               uint32_t B, uint32_t logT,
                                                               const void* __restrict__ small_tw,
                                                               const void* __restrict__ tw_hi,
@@ -105,8 +114,8 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
   const uint64_t U = blockIdx.x / cg_count;
   const uint64_t base = (U << (s_lo + B)) + (uint64_t)cg * T;
   const uint32_t shift = k - (s_lo + B);  // log2(n / N')
-  const char* sp = reinterpret_cast<const char*>(src);
-  char* d = reinterpret_cast<char*>(dst);
+  const char* sp = reinterpret_cast<const char*>(src) + (size_t)blockIdx.y * batch_stride;
+  char* d = reinterpret_cast<char*>(dst) + (size_t)blockIdx.y * batch_stride;
 
   for (uint32_t e = tid; e < tile; e += kNttThreads) {
     uint32_t c = e & (T - 1u), m = e >> logT;
@@ -118,33 +127,82 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
       else v = v * tw_lookup(tw_hi, tw_lo, L, ((cg * T + c) * r) << shift);
     }
     if (MODE == kPassPreScale) v = v * tw_lookup(sc_hi, sc_lo, Lc, __brev((uint32_t)p) >> (32u - k));
-    lds_store(lds, e, v);
+    lds_store(lds, tile, e, v);
   }
   __syncthreads();
 
-  for (uint32_t it = 0; it < B; it++) {
-    const uint32_t sl = DIF ? (B - 1u - it) : it;
-    const uint32_t half = 1u << sl;
-    for (uint32_t b = tid; b < (tile >> 1); b += kNttThreads) {
-      uint32_t c = b & (T - 1u), mb = b >> logT;
-      uint32_t j = mb & (half - 1u);
-      uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
-      uint32_t i0 = (m0 << logT) + c, i1 = i0 + (half << logT);
-      Fr u = lds_load(lds, i0), v = lds_load(lds, i1);
-      if (sl == 0u) {  // tile-local stage 0: every twiddle is W^0 = 1, no multiplication (uniform branch)
-        lds_store(lds, i0, u + v);
-        lds_store(lds, i1, u - v);
-      } else {
-        Fr tw = load_field<Fr>(reinterpret_cast<const char*>(small_tw) + 32 * (size_t)(j << (B - 1u - sl)));
+  const char* stw = reinterpret_cast<const char*>(small_tw);
+  uint32_t it = 0;
+  while (it < B) {
+    if (R4 && B - it >= 2u) {
+      // stages (sl, sl + 1), sl = the lower one: rows m0 + {0, h, 2h, 3h}, h = 2^sl, j = m0 mod h.
+      // twiddles: t1 = W_{2h}^j (stage sl, both pairs), t2 = W_{4h}^j and t3 = W_{4h}^(j + h) (stage sl + 1)
+      const uint32_t sl = DIF ? (B - 2u - it) : it;
+      const uint32_t h = 1u << sl;
+      for (uint32_t q = tid; q < (tile >> 2); q += kNttThreads) {
+        const uint32_t c = q & (T - 1u), mq = q >> logT;
+        const uint32_t j = mq & (h - 1u);
+        const uint32_t m0 = ((mq >> sl) << (sl + 2u)) | j;
+        const uint32_t i0 = (m0 << logT) + c, st = h << logT;
+        Fr x0 = lds_load(lds, tile, i0), x1 = lds_load(lds, tile, i0 + st), x2 = lds_load(lds, tile, i0 + 2u * st),
+           x3 = lds_load(lds, tile, i0 + 3u * st);
         if (DIF) {
-          lds_store(lds, i0, u + v);
-          lds_store(lds, i1, (u - v) * tw);
+          Fr a0 = x0 + x2, a2 = x0 - x2, a1 = x1 + x3, a3 = x1 - x3;
+          a3 = a3 * load_field<Fr>(stw + 32 * (size_t)((j + h) << (B - 2u - sl)));
+          if (sl) {   // sl == 0: j = 0, so t2 = t1 = 1 (uniform branch)
+            a2 = a2 * load_field<Fr>(stw + 32 * (size_t)(j << (B - 2u - sl)));
+            const Fr t1 = load_field<Fr>(stw + 32 * (size_t)(j << (B - 1u - sl)));
+            lds_store(lds, tile, i0, a0 + a1);
+            lds_store(lds, tile, i0 + st, (a0 - a1) * t1);
+            lds_store(lds, tile, i0 + 2u * st, a2 + a3);
+            lds_store(lds, tile, i0 + 3u * st, (a2 - a3) * t1);
+          } else {
+            lds_store(lds, tile, i0, a0 + a1);
+            lds_store(lds, tile, i0 + st, a0 - a1);
+            lds_store(lds, tile, i0 + 2u * st, a2 + a3);
+            lds_store(lds, tile, i0 + 3u * st, a2 - a3);
+          }
         } else {
-          v = v * tw;
-          lds_store(lds, i0, u + v);
-          lds_store(lds, i1, u - v);
+          if (sl) {
+            const Fr t1 = load_field<Fr>(stw + 32 * (size_t)(j << (B - 1u - sl)));
+            x1 = x1 * t1;
+            x3 = x3 * t1;
+          }
+          Fr a0 = x0 + x1, a1 = x0 - x1, a2 = x2 + x3, a3 = x2 - x3;
+          if (sl) a2 = a2 * load_field<Fr>(stw + 32 * (size_t)(j << (B - 2u - sl)));
+          a3 = a3 * load_field<Fr>(stw + 32 * (size_t)((j + h) << (B - 2u - sl)));
+          lds_store(lds, tile, i0, a0 + a2);
+          lds_store(lds, tile, i0 + st, a1 + a3);
+          lds_store(lds, tile, i0 + 2u * st, a0 - a2);
+          lds_store(lds, tile, i0 + 3u * st, a1 - a3);
         }
       }
+      it += 2u;
+    } else {
+      const uint32_t sl = DIF ? (B - 1u - it) : it;
+      const uint32_t half = 1u << sl;
+      for (uint32_t b = tid; b < (tile >> 1); b += kNttThreads) {
+        uint32_t c = b & (T - 1u), mb = b >> logT;
+        uint32_t j = mb & (half - 1u);
+        uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
+        uint32_t i0 = (m0 << logT) + c, i1 = i0 + (half << logT);
+        Fr u = lds_load(lds, tile, i0), v = lds_load(lds, tile, i1);
+        if (sl == 0u) {  // tile-local stage 0: every twiddle is W^0 = 1, no multiplication (uniform branch)
+          lds_store(lds, tile, i0, u + v);
+          lds_store(lds, tile, i1, u - v);
+        } else {
+          Fr tw = load_field<Fr>(stw + 32 * (size_t)(j << (B - 1u - sl)));
+          if (DIF) {
+            lds_store(lds, tile, i0, u + v);
+            lds_store(lds, tile, i1, (u - v) * tw);
+          } else {
+            v = v * tw;
+            lds_store(lds, tile, i0, u + v);
+            lds_store(lds, tile, i1, u - v);
+          }
+        }
+      }
+      it += 1u;
     }
     __syncthreads();
   }
@@ -152,7 +210,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
   for (uint32_t e = tid; e < tile; e += kNttThreads) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
-    Fr v = lds_load(lds, e);
+    Fr v = lds_load(lds, tile, e);
     if (DIF && s_lo > 0) {
       uint32_t r = __brev(m) >> (32u - B);
       if (tw_direct) v = v * load_field<Fr>(reinterpret_cast<const char*>(tw_direct) + 32 * (((size_t)r << s_lo) + cg * T + c));
@@ -348,11 +406,20 @@ struct NttEngine {
   // mode applies to the pass over stages [0, B) (the last DIF pass / the first DIT pass). kPassPreScale: (sc_hi,
   // sc_lo, Lc) two-level table of the per-element factor. kPassBitrevOut: the transform reads `d_data`, uses `tmp`
   // (n elements) for the intermediate passes and leaves the NATURAL-order result, times `post`, in d_data.
+  // batch vectors of 2^k elements, batch_stride bytes apart, go through every pass together (grid.y = batch).
+  static bool radix4() {   // ZKPOA_NTT_RADIX=2: one stage per barrier, as before r03 (A/B measurement)
+    static const bool v = [] {
+      const char* e = getenv("ZKPOA_NTT_RADIX");
+      return !(e && !strcmp(e, "2"));
+    }();
+    return v;
+  }
   template <bool DIF>
   void run_passes(hipStream_t st, void* d_data, uint32_t k, bool inverse, int mode = kPassPlain,
                   const void* sc_hi = nullptr, const void* sc_lo = nullptr, uint32_t Lc = 0, void* tmp = nullptr,
-                  const HFr* post = nullptr) {
-    if (k == 0) return;
+                  const HFr* post = nullptr, uint32_t batch = 1, size_t batch_stride = 0) {
+    if (k == 0 || batch == 0) return;
+    if (mode == kPassBitrevOut && batch != 1) throw HipError("ntt: the natural-order form takes one vector at a time");
     const NttTables& t = tables(st, k, inverse);
     auto plan = ntt_plan(k);
     const Fr post_d = to_dev(post ? *post : HFr::one());
@@ -370,21 +437,31 @@ struct NttEngine {
         src = idx == 0 ? d_data : tmp;
         dst = idx + 1 == plan.size() ? d_data : tmp;
       }
-#define ZK_NTT_PASS(MODE_)                                                                                              \
-  hipLaunchKernelGGL((ntt_pass_kernel<DIF, MODE_>), dim3(grid), dim3(kNttThreads), lds_bytes, st, src, dst, k, ps.s_lo,  \
-                     ps.B, ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi, (const void*)t.lo, t.L, direct,     \
-                     sc_hi, sc_lo, Lc, post_d)
+#define ZK_NTT_PASS_R(MODE_, R4_)                                                                                        \
+  hipLaunchKernelGGL((ntt_pass_kernel<DIF, MODE_, R4_>), dim3(grid, batch), dim3(kNttThreads), lds_bytes, st, src, dst,   \
+                     batch_stride, k, ps.s_lo, ps.B, ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi,          \
+                     (const void*)t.lo, t.L, direct, sc_hi, sc_lo, Lc, post_d)
+#define ZK_NTT_PASS(MODE_)              \
+  do {                                  \
+    if (radix4()) ZK_NTT_PASS_R(MODE_, true); \
+    else ZK_NTT_PASS_R(MODE_, false);   \
+  } while (0)
       if (special && mode == kPassPreScale) ZK_NTT_PASS(kPassPreScale);
       else if (special && mode == kPassBitrevOut) ZK_NTT_PASS(kPassBitrevOut);
       else ZK_NTT_PASS(kPassPlain);
 #undef ZK_NTT_PASS
+#undef ZK_NTT_PASS_R
     }
   }
 
   // natural -> bit-reversed, root w (or w^-1)
-  void dif(hipStream_t st, void* d, uint32_t k, bool inverse) { run_passes<true>(st, d, k, inverse); }
+  void dif(hipStream_t st, void* d, uint32_t k, bool inverse, uint32_t batch = 1, size_t stride = 0) {
+    run_passes<true>(st, d, k, inverse, kPassPlain, nullptr, nullptr, 0, nullptr, nullptr, batch, stride);
+  }
   // bit-reversed -> natural
-  void dit(hipStream_t st, void* d, uint32_t k, bool inverse) { run_passes<false>(st, d, k, inverse); }
+  void dit(hipStream_t st, void* d, uint32_t k, bool inverse, uint32_t batch = 1, size_t stride = 0) {
+    run_passes<false>(st, d, k, inverse, kPassPlain, nullptr, nullptr, 0, nullptr, nullptr, batch, stride);
+  }
 
   // Fr.fft / Fr.ifft semantics: natural order in and out. The bit-reversal and the 1/n of the inverse ride on the
   // last DIF pass's store (no permutation kernel, no scaling kernel); multi-pass sizes go through a scratch buffer
@@ -408,14 +485,14 @@ struct NttEngine {
 
   // evaluations on the domain -> evaluations on the odd coset (ifft, batchApplyKey(1, inc), fft): the coset shift
   // inc^j / n is applied by the forward transform's first pass as it loads (no separate scaling pass)
-  void to_odd_coset(hipStream_t st, void* d, uint32_t k) {
+  void to_odd_coset(hipStream_t st, void* d, uint32_t k, uint32_t batch = 1, size_t stride = 0) {
     if (k == 0) return;  // n = 1: constant polynomial
     uint64_t n = 1ull << k;
     HFr inc = (k == 28) ? HFr::from_u64(25) : hfr_root_of_unity(k + 1);
     HFr ninv = HFr::from_u64(n).inv();
     auto tb = pow_tables(st, k, inc, ninv, k);
-    dif(st, d, k, true);
-    run_passes<false>(st, d, k, false, kPassPreScale, tb.first, tb.second, (k + 1) / 2);
+    dif(st, d, k, true, batch, stride);
+    run_passes<false>(st, d, k, false, kPassPreScale, tb.first, tb.second, (k + 1) / 2, nullptr, nullptr, batch, stride);
   }
 
   // the part of to_odd_coset between the two exchanges when the transform is split over G ranks

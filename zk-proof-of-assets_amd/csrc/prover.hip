@@ -581,9 +581,7 @@ void h_chain(zkpoa_context* ctx, hipStream_t st, const uint32_t* row_ptr, const 
   if (n_long)
     hipLaunchKernelGGL(abc_long_rows_kernel, dim3((n_long + 3) / 4), dim3(256), 0, st, row_ptr, sig, vals, d_witness,
                        long_list, n_long, 0u, 0u, (void*)A, (void*)B, (void*)C);
-  ntt_to_odd_coset(ctx, st, A, power);
-  ntt_to_odd_coset(ctx, st, B, power);
-  ntt_to_odd_coset(ctx, st, C, power);
+  ntt_to_odd_coset(ctx, st, A, power, 3, (size_t)domain * 32);   // A, B and C together: 4-6 launches instead of 12-18
   hipLaunchKernelGGL(abc_join_kernel, dim3(grid), dim3(256), 0, st, (const void*)A, (const void*)B, (const void*)C,
                      domain, (void*)A);
 }
@@ -613,7 +611,7 @@ void split_stage1(zkpoa_context* ctx, const zkpoa_zkey* zk, void* d_x) {
                        (const void*)zk->d_witness, (const uint32_t*)zk->d_long, zk->n_long,
                        zk->csr_local ? 0u : zk->split_log, zk->csr_local ? 0u : zk->split_rank, (void*)A, (void*)B,
                        (void*)C);
-  for (char* X : {A, B, C}) ntt_dif(ctx, st, X, kM, true);
+  ntt_dif(ctx, st, A, kM, true, 3, (size_t)M * 32);
   hipLaunchKernelGGL((split_pack_kernel<true>), dim3((uint32_t)(((uint64_t)6 * M + 255) / 256)), dim3(256), 0, st,
                      (const uint4*)zk->d_abc, (uint4*)d_x, M, Q);
   ZK_HIP(hipGetLastError());
@@ -636,7 +634,7 @@ void split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zk, const void* d_x) {
   char* C = B + (size_t)M * 32;
   hipLaunchKernelGGL((split_pack_kernel<false>), dim3((uint32_t)(((uint64_t)6 * M + 255) / 256)), dim3(256), 0, st,
                      (const uint4*)d_x, (uint4*)zk->d_abc, M, Q);
-  for (char* X : {A, B, C}) ntt_dit(ctx, st, X, kM, false);
+  ntt_dit(ctx, st, A, kM, false, 3, (size_t)M * 32);
   hipLaunchKernelGGL(abc_join_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const void*)A, (const void*)B,
                      (const void*)C, M, zk->d_abc);
   ZK_HIP(hipGetLastError());
@@ -1144,7 +1142,8 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
   try {
     auto alloc = [](void** p, uint64_t bytes) { ZK_HIP(hipMalloc(p, bytes ? bytes : 1)); };
     alloc(reinterpret_cast<void**>(&d_cflag), 64);
-    ZK_HIP(hipMemset(d_cflag, 0, 64));
+    ZK_HIP(hipMemsetAsync(d_cflag, 0, 64, ctx->dev.lanes[0].stream));   // stream-ordered, then waited for: the range checks
+    ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[0].stream));              // that OR into it run on other (non-blocking) streams
     alloc(&k->d_witness, m * 32);
     alloc(&d_recs, zk->nCoefs * 44);
     alloc(reinterpret_cast<void**>(&k->d_flag), 1024);

@@ -99,11 +99,12 @@ void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own
                   uint8_t* out, float* ms2);
 // ntt.hip
 void ntt_prepare(zkpoa_context* ctx, hipStream_t st, uint32_t k);  // builds twiddle tables (hipMalloc) once per k
-void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k);
+// batch > 1: that many vectors of 2^k elements, `stride` bytes apart, transformed together (one launch per pass)
+void ntt_to_odd_coset(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, uint32_t batch = 1, size_t stride = 0);
 void ntt_natural(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
 // unscaled, unpermuted halves of a transform: DIF natural -> bit-reversed, DIT bit-reversed -> natural
-void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
-void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse);
+void ntt_dif(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse, uint32_t batch = 1, size_t stride = 0);
+void ntt_dit(zkpoa_context* ctx, hipStream_t st, void* d_data, uint32_t k, bool inverse, uint32_t batch = 1, size_t stride = 0);
 // H-scalar chain split over G ranks: the step between the two exchanges (ntt.hip.h, ntt_split_mid_kernel)
 void ntt_split_mid(zkpoa_context* ctx, hipStream_t st, const void* in, void* out, uint32_t k, uint32_t G, uint32_t h,
                    uint32_t rank_stride);
