@@ -26,8 +26,9 @@ sys.path.insert(0, ROOT)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
-VALU_PEAK_GADDS = 12.1      # XYZZ mixed additions/s: register-only loop of the same addition on one MI355X at its best
-                            # occupancy (tools/microbench.hip: 11.6 at 3 waves/SIMD, 12.1 at 4)
+VALU_PEAK_GADDS = 12.6      # XYZZ mixed additions/s: register-only loop of the same addition (8 M + 2 dedicated S) on one
+                            # MI355X at its best occupancy (tools/microbench.hip, r03: 12.15 at 3 waves/SIMD, 12.60 at 4;
+                            # r02, squarings as products: 11.6 / 12.1)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
 DTYPE = "u32x8 (254-bit modular integer)"
@@ -538,7 +539,8 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
 
 
 # ---------------------------------------------------------------------------------------------------------------
-MODMUL_PEAK_G = 130.0       # 254-bit Montgomery products/s, register-only loop on one MI355X (tools/microbench2.hip)
+MODMUL_PEAK_G = 140.0       # 254-bit Montgomery products/s, register-only loop on one MI355X (tools/microbench.hip, r03: a * a
+                            # 139.8 G/s at 8 waves/SIMD, the dedicated square 170.2 G/s; r02 quoted 130 from 4 waves/SIMD)
 POSEIDON_MODMULS = 8 * 18 + 4 + 57 * 8 + 3   # per hash as the kernel computes it: full rounds 3 S-boxes + 9 MDS products,
                                             # one 2 x 2 product, sparse partial rounds 3 + 5, form changes (poseidon.hip)
 

@@ -320,6 +320,82 @@ def test_setup_outputs_are_atomic_and_inputs_range_checked(ctx, zk, tmp_path):
     assert not (tmp_path / "out.zkey").exists()
 
 
+# ---- zkey new at the reference's layer-one shape, every point section checked --------------------
+def _weighted_dlog(rho, terms, dl_of_constraint):
+    """sum over the terms (c, s, coef) of rho[s] * coef * dl(c) mod r, in vectorised 16-bit pieces (exact)."""
+    c, s, coef = terms
+    x = rho[s].astype(np.uint64) * dl_of_constraint(c).astype(np.uint64)        # < 2^29 * 2^35
+    x16 = [((x >> np.uint64(16 * j)) & np.uint64(0xFFFF)) for j in range(4)]
+    total = 0
+    for i in range(16):
+        ci = (coef[:, i // 4] >> np.uint64(16 * (i % 4))) & np.uint64(0xFFFF)
+        if not ci.any():
+            continue
+        for j in range(4):
+            total += int(np.dot(ci, x16[j])) << (16 * (i + j))                   # < 2^32 * 2^23 terms: no overflow
+    return total % R
+
+
+def test_zkey_new_layer_one_shape_known_dlog(ctx, zk, tmp_path):
+    """`zkpoa-setup zkey new` at the layer_one(2 sigs) shape (2^21 domain, 2,083,343 wires, 8.4 M terms; shape from
+    tests/4_sigs_2_batches_12_height/benchmarks.txt:17-23) on format-valid files whose ceremony points are known
+    multiples of the generators. Every point section of the key is checked in full: for random 29-bit weights rho_s,
+    sum_s rho_s * Section[s] (one MSM over the section, G1 or G2) must equal (sum_terms rho_s * coef * dlog(point)) * G
+    computed with integer arithmetic and ONE oracle scalar multiplication -- a wrong point passes with probability
+    2^-29. Section 9 (H) must be the odd points of the 2n-point Lagrange level; the key must load in the prover."""
+    import subprocess
+    import time
+    from oracle.py import groth16 as g16
+    from setup_files import PTAU_PROGRESSIONS, write_full_shape_inputs
+    k, m, n_pub = 21, 2083343, 1
+    n = 1 << k
+    t0 = time.time()
+    terms = write_full_shape_inputs(ctx, k, m, str(tmp_path), seed=3, n_public=n_pub)
+    t_in = time.time() - t0
+    t0 = time.time()
+    rc = subprocess.run([zk.SETUP_BIN, "zkey", "new", "c.r1cs", "pot.ptau", "c_0.zkey"], cwd=tmp_path, capture_output=True,
+                        text=True, timeout=600)
+    assert rc.returncode == 0, rc.stderr
+    t_new = time.time() - t0
+    zkey = (tmp_path / "c_0.zkey").read_bytes()
+    secs = {t: lst[0] for t, lst in g16.read_binfile(zkey, "zkey", 1).items()}
+    sec = lambda t: zkey[secs[t][0]:secs[t][0] + secs[t][1]]
+    assert secs[5][1] == m * 64 and secs[7][1] == m * 128 and secs[8][1] == (m - n_pub - 1) * 64 and secs[9][1] == n * 64
+    nr = np.random.default_rng(99)
+    rho = nr.integers(1, 1 << 29, size=m, dtype=np.int64)
+    rho_bytes = np.zeros((m, 4), dtype=np.uint64)
+    rho_bytes[:, 0] = rho.astype(np.uint64)
+    rho_bytes = rho_bytes.tobytes()
+    lvl = (1 << k) - 1                                    # first point of the circuit's Lagrange level in a section
+    dl = lambda s: (lambda c: PTAU_PROGRESSIONS[s][0] + PTAU_PROGRESSIONS[s][1] * (lvl + c))
+    pub_rows = (np.arange(terms["n_cons"], terms["n_cons"] + n_pub + 1, dtype=np.int64), np.arange(n_pub + 1, dtype=np.int64),
+                np.tile(np.array([1, 0, 0, 0], dtype=np.uint64), (n_pub + 1, 1)))
+    A_terms = tuple(np.concatenate([x, y]) for x, y in zip(terms["A"], pub_rows))
+    # section 5 (A over tau*G1), 6 / 7 (B over tau*G1 / tau*G2)
+    assert g16.g1_from_bytes(ctx.msm_g1(sec(5), rho_bytes, m)) == bn.g1_mul(bn.G1_GEN, _weighted_dlog(rho, A_terms, dl(12)))
+    eB = _weighted_dlog(rho, terms["B"], dl(12))
+    assert g16.g1_from_bytes(ctx.msm_g1(sec(6), rho_bytes, m)) == bn.g1_mul(bn.G1_GEN, eB)
+    eB2 = _weighted_dlog(rho, terms["B"], dl(13))
+    assert g16.g2_from_bytes(ctx.msm_g2(sec(7), rho_bytes, m)) == bn.g2_mul(bn.G2_GEN, eB2)
+    # sections 3 + 8: IC and C are one vector K[s] = A over beta*tau*G1 + B over alpha*tau*G1 + C over tau*G1
+    eK = (_weighted_dlog(rho, A_terms, dl(15)) + _weighted_dlog(rho, terms["B"], dl(14)) +
+          _weighted_dlog(rho, terms["C"], dl(12))) % R
+    assert g16.g1_from_bytes(ctx.msm_g1(sec(3) + sec(8), rho_bytes, m)) == bn.g1_mul(bn.G1_GEN, eK)
+    # section 9: H[i] = point 2 i + 1 of the 2n-point level of section 12
+    a12, b12 = PTAU_PROGRESSIONS[12]
+    h = sec(9)
+    for i in (0, 1, 12345, n // 2, n - 1):
+        assert g16.g1_from_bytes(h, 64 * i) == bn.g1_mul(bn.G1_GEN, a12 + b12 * ((2 << k) - 1 + 2 * i + 1))
+    rho_h = np.zeros((n, 4), dtype=np.uint64)
+    rho_h[:, 0] = nr.integers(1, 1 << 20, size=n, dtype=np.uint64)         # 2^20 * 2^21 * 2^21 terms < 2^63
+    idx = np.arange(n, dtype=np.uint64)
+    eH = (int(rho_h[:, 0].sum()) * (a12 + b12 * ((2 << k) - 1 + 1)) + 2 * b12 * int(np.dot(rho_h[:, 0], idx))) % R
+    assert g16.g1_from_bytes(ctx.msm_g1(h, rho_h.tobytes(), n)) == bn.g1_mul(bn.G1_GEN, eH)
+    key = ctx.load_zkey(zkey)                             # section sizes, coordinate / coefficient range checks
+    key.close()
+    print("layer-one shape: inputs written in %.1f s, zkpoa-setup zkey new %.2f s, 1.08 GB key checked" % (t_in, t_new))
+
+
 # ---- `snarkjs wtns check` -------------------------------------------------------------------------------------------
 def test_wtns_check(ctx, zk, tmp_path):
     import subprocess

@@ -2,7 +2,7 @@
 usage: python tools/build_profile_summary.py [round, default r02]"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", "profiles_" + RND)
 DST = os.path.join(ROOT, "profiles")
 for old in glob.glob(os.path.join(DST, RND + "_*")):
@@ -55,7 +55,7 @@ out["calibration"] = {
     "expected_write_KiB": wr, "WRITE_SIZE_KiB": w[k][1], "write_ratio": w[k][1] / wr,
     "conclusion": "for this access pattern both counters read the true bytes within 5 %: no x2 correction applied"}
 for tag, name in (("msm20", "msm_g1_2p20"), ("msm20fb", "msm_g1_2p20_fixed_base"), ("msm26", "msm_g1_2p26"),
-                  ("msm26fb", "msm_g1_2p26_fixed_base")):
+                  ("msm26fb", "msm_g1_2p26_fixed_base"), ("msm20k128", "msm_g1_2p20_pieces_of_128")):
     if not glob.glob(os.path.join(SRC, "pmc_%s_FETCH_SIZE" % tag)):
         continue
     f, w = summarize(tag, "FETCH_SIZE"), summarize(tag, "WRITE_SIZE")
@@ -72,7 +72,37 @@ for tag, name in (("msm20", "msm_g1_2p20"), ("msm20fb", "msm_g1_2p20_fixed_base"
                          "WRITE_SIZE_KiB": w.get(kk, (0, 0))[1],
                          "bytes_per_launch": (fc * f[kk][1] + w.get(kk, (0, 0))[1]) * 1024}
     out["workloads"][name] = ks
+# whole proofs (bench.py --serial under --pmc): HBM bytes per proof = all dispatches of the proof's kernels / proofs run.
+# Kernels that only run once per key (table building, CSR build, query compaction, twiddle tables, synthetic inputs) are
+# left out; streaming kernels get the x2 read correction as above, gathers do not.
+ONCE = ("msm_table_", "gen_bases", "query_", "abc_count", "abc_scatter", "abc_long_list", "fr_pow_table", "ntt_direct_table",
+        "to_affine", "strided_copy", "msm_density")
+STREAMING = ("digits", "sort_", "scan_", "piece_", "ntt_pass", "abc_join", "range_check", "gather32", "gather_bc32")
+for tag, name in (("prove21", "prove_2p21"), ("prove26", "prove_2p26")):
+    if not glob.glob(os.path.join(SRC, "pmc_%s_FETCH_SIZE" % tag)):
+        continue
+    f, w = summarize(tag, "FETCH_SIZE"), summarize(tag, "WRITE_SIZE")
+    line = last_json_line(os.path.join(SRC, "pmc_%s_FETCH_SIZE.log" % tag))
+    proofs = json.loads(line)["config"]["proofs_run_in_process"] if line else None
+    if not proofs:
+        continue
+    ks, total = {}, 0.0
+    for kk in f:
+        short = kk.split("(")[0].replace("void ", "")
+        if "zkpoa::" not in kk or any(t in short for t in ONCE):
+            continue
+        fc = 2.0 if any(t in short for t in STREAMING) else 1.0
+        b = (fc * f[kk][1] + w.get(kk, (0, 0))[1]) * 1024 * f[kk][0]
+        ks[short] = {"dispatches": f[kk][0], "FETCH_SIZE_KiB": f[kk][1], "fetch_correction": fc,
+                     "WRITE_SIZE_KiB": w.get(kk, (0, 0))[1], "bytes_all_dispatches": b}
+        total += b
+    ks["per_proof (all kernels of a proof, stages serialised; %d proofs in the profiled process)" % proofs] = {
+        "bytes_per_launch": total / proofs}
+    out["workloads"][name] = ks
 json.dump(out, open(os.path.join(DST, RND + "_pmc_hbm_traffic.json"), "w"), indent=1)
+tl = os.path.join(SRC, "timeline_prove21_serial.txt")
+if os.path.exists(tl):
+    shutil.copy(tl, os.path.join(DST, RND + "_timeline_prove21_serial.txt"))
 for extra in ("pcie_inclusive_%s.log" % RND,):
     p = os.path.join(ROOT, "gpurun_out", extra)
     if os.path.exists(p):

@@ -312,7 +312,9 @@ inline std::vector<NttPassDesc> ntt_plan(uint32_t k) {
     uint32_t s = b0;
     for (uint32_t i = 0; i < npass; i++) {
       uint32_t b = rest / npass + (i < rest % npass ? 1 : 0);
-      v.push_back({s, b, kNttTileLog - kNttStridedB});
+      // always a full 2048-element tile: fewer rows = more columns (r02 kept 8 columns, so a 5- or 6-stage pass ran
+      // on 256- or 512-element tiles with most of the workgroup idle: 2^22 and 2^24 were off the curve)
+      v.push_back({s, b, kNttTileLog - b});
       s += b;
     }
   }
