@@ -5,9 +5,12 @@ set -u
 ROUND=${ROUND:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$ROUND
-rm -rf $O; mkdir -p $O
+PART=${PART:-all}      # 1 = bench lines + kernel stats, 2 = PMC passes (a gpurun call is at most 20 minutes)
+[ "$PART" != 2 ] && rm -rf $O
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
+if [ "$PART" != 2 ]; then
 $B > $O/bench_default.json.log 2>$O/bench_default.err; echo "bench default (headline + also legs) rc=$?"
 $B --no-also --no-cpu-baseline --inflight 1 > $O/bench_msm_g1_2p20_inflight1.json.log 2>/dev/null
 $B --no-also --no-cpu-baseline --fixed-base --inflight 1 > $O/bench_msm_g1_2p20_fixed_base_inflight1.json.log 2>/dev/null
@@ -29,6 +32,8 @@ $S -d $O/stats_prove21_serial -- $B --workload prove_2p21 --steps 6 --warmup 1 -
 rocprofv3 --kernel-trace --output-format csv -d $O/trace_serial21 -- python3 $R/tools/trace_serial_prove.py 21 > $O/trace_serial21.log 2>&1
 python3 $R/tools/trace_timeline.py $O/trace_serial21 > $O/timeline_prove21_serial.txt 2>&1
 echo "stats done"
+fi
+if [ "$PART" != 1 ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
   P="rocprofv3 --pmc $c --kernel-trace --output-format csv"
   $P -d $O/pmc_calib_$c -- $R/tools/gather_calib > $O/pmc_calib_$c.log 2>&1
@@ -45,6 +50,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   $P -d $O/pmc_prove26_$c -- $B --workload prove_2p26 --steps 1 --warmup 0 --serial --no-cpu-baseline > $O/pmc_prove26_$c.log 2>&1
 done
 echo "pmc done"
+fi
 # keep the merged output small: drop the per-dispatch traces of the big runs
 find $O -name '*kernel_trace.csv' -size +4M -delete
 find $O -name '*counter_collection.csv' -size +8M -delete

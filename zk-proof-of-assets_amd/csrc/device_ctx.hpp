@@ -173,9 +173,10 @@ struct DeviceCtx {
         // level matters little (within 3 %); ZKPOA_LANE_PRIO = flat | none | ladder2 selects the other patterns tried.
         const char* pe = getenv("ZKPOA_LANE_PRIO");
         const bool flat = pe && !strcmp(pe, "flat"), none = pe && !strcmp(pe, "none"), ladder2 = pe && !strcmp(pe, "ladder2");
-        static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1};
+        const bool top1 = pe && !strcmp(pe, "top1");   // the chain's lane alone at the top level
+        static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1}, kTop1[6] = {2, 1, 1, 0, 0, 0};
         for (int i = 1; i < kEagerLanes; i++)
-          lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
+          lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : top1 ? kTop1[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
       } catch (...) {
         bg_err_ = std::current_exception();
         {

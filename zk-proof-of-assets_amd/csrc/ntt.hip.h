@@ -108,7 +108,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
                                                               const void* __restrict__ sc_hi,
                                                               const void* __restrict__ sc_lo, uint32_t Lc, Fr post) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const uint32_t T = 1u << logT, tile = 1u << (B + logT), tid = threadIdx.x;
+  const uint32_t T = 1u << logT, tile = 1u << (B + logT), tid = threadIdx.x, nthr = blockDim.x;
   const uint32_t cg_count = (1u << s_lo) >> logT;
   const uint32_t cg = blockIdx.x % cg_count;
   const uint64_t U = blockIdx.x / cg_count;
@@ -117,7 +117,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
   const char* sp = reinterpret_cast<const char*>(src) + (size_t)blockIdx.y * batch_stride;
   char* d = reinterpret_cast<char*>(dst) + (size_t)blockIdx.y * batch_stride;
 
-  for (uint32_t e = tid; e < tile; e += kNttThreads) {
+  for (uint32_t e = tid; e < tile; e += nthr) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
     Fr v = load_field<Fr>(sp + 32 * p);
@@ -139,7 +139,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
       // twiddles: t1 = W_{2h}^j (stage sl, both pairs), t2 = W_{4h}^j and t3 = W_{4h}^(j + h) (stage sl + 1)
       const uint32_t sl = DIF ? (B - 2u - it) : it;
       const uint32_t h = 1u << sl;
-      for (uint32_t q = tid; q < (tile >> 2); q += kNttThreads) {
+      for (uint32_t q = tid; q < (tile >> 2); q += nthr) {
         const uint32_t c = q & (T - 1u), mq = q >> logT;
         const uint32_t j = mq & (h - 1u);
         const uint32_t m0 = ((mq >> sl) << (sl + 2u)) | j;
@@ -181,7 +181,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
     } else {
       const uint32_t sl = DIF ? (B - 1u - it) : it;
       const uint32_t half = 1u << sl;
-      for (uint32_t b = tid; b < (tile >> 1); b += kNttThreads) {
+      for (uint32_t b = tid; b < (tile >> 1); b += nthr) {
         uint32_t c = b & (T - 1u), mb = b >> logT;
         uint32_t j = mb & (half - 1u);
         uint32_t m0 = ((mb >> sl) << (sl + 1u)) | j;
@@ -207,7 +207,7 @@ static __global__ __launch_bounds__(kNttThreads) void ntt_pass_kernel(const void
     __syncthreads();
   }
 
-  for (uint32_t e = tid; e < tile; e += kNttThreads) {
+  for (uint32_t e = tid; e < tile; e += nthr) {
     uint32_t c = e & (T - 1u), m = e >> logT;
     uint64_t p = base + ((uint64_t)m << s_lo) + c;
     Fr v = lds_load(lds, tile, e);
@@ -296,9 +296,25 @@ struct NttPassDesc {
 };
 
 // passes in DIT order (stage 0 upwards); DIF runs them in reverse
+// Tile size of a transform: 2048 elements (64 KiB: two workgroups of 512 threads per CU) up to 2^22, where it makes
+// the transform two passes; above that 1024 elements (32 KiB: FOUR workgroups of 256 threads per CU). The pass count
+// is the same there (2^26 = 10 + 8 + 8 stages instead of 11 + 8 + 7), and a workgroup's load -> butterflies -> store
+// phases do not overlap with each other, only with the other workgroups of the CU: four of them out of step keep the
+// multipliers busy while one loads or stores. ZKPOA_NTT_TILE=10|11 forces either (measurement).
+inline uint32_t ntt_tile_log(uint32_t k) {
+  static const int forced = [] {
+    const char* e = getenv("ZKPOA_NTT_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 10 || forced == 11) return (uint32_t)forced;
+  return k >= 23 ? 10u : 11u;
+}
+
 inline std::vector<NttPassDesc> ntt_plan(uint32_t k) {
   std::vector<NttPassDesc> v;
   if (k == 0) return v;
+  const uint32_t kNttTileLog = ntt_tile_log(k);   // shadows the constant: everything below is per transform size
+  const uint32_t kNttMaxStridedB = kNttTileLog - 1;
   uint32_t b0 = k < kNttTileLog ? k : kNttTileLog;
   v.push_back({0, b0, 0});
   uint32_t rest = k - b0;
@@ -429,6 +445,8 @@ struct NttEngine {
       const NttPassDesc& ps = DIF ? plan[plan.size() - 1 - idx] : plan[idx];
       uint32_t tile_log = ps.B + ps.logT;
       uint32_t grid = 1u << (k - tile_log);
+      // a quarter of the tile: one radix-4 group (or two radix-2 butterflies) per thread and stage pair
+      const uint32_t nthreads = tile_log >= 8 ? (tile_log >= 11 ? kNttThreads : (1u << (tile_log - 2))) : 64u;
       size_t lds_bytes = (size_t)32 << tile_log;
       auto dit = t.direct.find(ps.s_lo);
       const void* direct = dit == t.direct.end() ? nullptr : dit->second;
@@ -440,7 +458,7 @@ struct NttEngine {
         dst = idx + 1 == plan.size() ? d_data : tmp;
       }
 #define ZK_NTT_PASS_R(MODE_, R4_)                                                                                        \
-  hipLaunchKernelGGL((ntt_pass_kernel<DIF, MODE_, R4_>), dim3(grid, batch), dim3(kNttThreads), lds_bytes, st, src, dst,   \
+  hipLaunchKernelGGL((ntt_pass_kernel<DIF, MODE_, R4_>), dim3(grid, batch), dim3(nthreads), lds_bytes, st, src, dst,      \
                      batch_stride, k, ps.s_lo, ps.B, ps.logT, (const void*)t.small.at(ps.B), (const void*)t.hi,          \
                      (const void*)t.lo, t.L, direct, sc_hi, sc_lo, Lc, post_d)
 #define ZK_NTT_PASS(MODE_)              \
