@@ -184,3 +184,29 @@ def test_split_chain_supported():
     assert not sharding.split_chain_supported(3, 1 << 20)      # replicated chain instead
     assert not sharding.split_chain_supported(8, 32)
     assert not sharding.split_chain_supported(1, 1 << 20)
+
+
+def test_block_cyclic_blocks_partition_the_section(zk):
+    """sharding.block_cyclic_blocks (what bench.py --gpus N and the prover's own multi-GPU path deal out, include/
+    zkpoa_prover.h ZKPOA_SHARD_BLOCK_CYCLIC): the ranks' blocks cover [0, n) exactly once, every block but the globally
+    last is full, rank sizes differ by at most one block, and the flag word packs as the header's macros do."""
+    import random
+    from zkpoa_amd.sharding import block_cyclic_blocks
+    rng = random.Random(5)
+    for _ in range(300):
+        n, world, L = rng.randrange(0, 100000), rng.randrange(1, 9), rng.randrange(4, 13)
+        seen, sizes = [], []
+        for rank in range(world):
+            runs = block_cyclic_blocks(n, rank, world, L)
+            assert all(start % (1 << L) == 0 and (start >> L) % world == rank for start, _ in runs)
+            assert all(cnt == (1 << L) for _, cnt in runs[:-1])
+            seen += [(s, c) for s, c in runs]
+            sizes.append(sum(c for _, c in runs))
+        seen.sort()
+        assert sum(c for _, c in seen) == n
+        pos = 0
+        for s, c in seen:
+            assert s == pos and c > 0
+            pos += c
+        assert max(sizes) - min(sizes) <= (1 << L)
+    assert zk.shard_flags(True, 16) == 0x1001 and zk.shard_flags(False, 0) == 0 and zk.shard_flags(False, 7) == 0x700
