@@ -26,9 +26,12 @@ sys.path.insert(0, ROOT)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
-VALU_PEAK_GADDS = 12.6      # XYZZ mixed additions/s: register-only loop of the same addition (8 M + 2 dedicated S) on one
-                            # MI355X at its best occupancy (tools/microbench.hip, r03: 12.15 at 3 waves/SIMD, 12.60 at 4;
-                            # r02, squarings as products: 11.6 / 12.1)
+VALU_PEAK_GADDS = 13.6      # XYZZ mixed additions/s the integer pipe allows on one MI355X, from the measured rates of its parts
+                            # (tools/microbench.hip, r03, 8 waves/SIMD): 8 products at 139.8 G/s + 2 squares at 170.2 G/s + 7
+                            # additions / subtractions of 24 instructions each (0.62 of a product's 272) = 73.4 ps per addition.
+                            # The register-only loop of the same addition reaches 12.6 G/s at 4 waves/SIMD (12.15 at 3) and was
+                            # r02's "peak" -- the kernel, whose base loads hide under the arithmetic, runs above it, so it was
+                            # not a ceiling
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
 DTYPE = "u32x8 (254-bit modular integer)"

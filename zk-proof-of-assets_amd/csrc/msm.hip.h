@@ -603,13 +603,31 @@ static __global__ __launch_bounds__(256, AccumWaves<F>::N) void msm_accum0_kerne
   uint32_t end = off0[b] + cnt;
   if (end - start > K0) end = start + K0;
   XYZZ<F> acc = XYZZ<F>::inf();
-  uint32_t e = sorted[start];
+  // The piece's entry indices are read FOUR at a time (one aligned 16-byte load per four additions). Every lane walks
+  // its own run of `sorted`, so a 4-byte read per addition touched the lane's 64-byte line sixteen separate times,
+  // ~5 us apart, with the base gathers of 200 k other lanes streaming through the L2 in between: the line was fetched
+  // again most of the time (r02 PMC: 1.63 GB fetched per 2^20 launch against 1.07 GB of bases + 0.07 GB of indices,
+  // unchanged with four times longer pieces -- so it was the walk, not the per-piece metadata; 1.31 GB with this).
+  // The words of a block that lie outside [start, end) belong to neighbouring pieces and are simply not used; `sorted`
+  // is 256-byte aligned and padded (Arena::take).
+  const uint4* sorted4 = reinterpret_cast<const uint4*>(sorted);
+  uint32_t blk = start >> 2;
+  uint4 cache = sorted4[blk];
+  auto entry = [&](uint32_t k) -> uint32_t {
+    if ((k >> 2) != blk) {
+      blk = k >> 2;
+      cache = sorted4[blk];
+    }
+    const uint32_t i = k & 3u;
+    return i == 0u ? cache.x : (i == 1u ? cache.y : (i == 2u ? cache.z : cache.w));
+  };
+  uint32_t e = entry(start);
   Affine<F> p = load_affine<F>(bases, e & 0x7fffffffu);
   for (uint32_t k = start; k < end; k++) {
     uint32_t e_cur = e;
     Affine<F> p_cur = p;
     if (k + 1 < end) {  // prefetch the next base under this addition
-      e = sorted[k + 1];
+      e = entry(k + 1);
       p = load_affine<F>(bases, e & 0x7fffffffu);
     }
     xyzz_add_affine(acc, p_cur, (e_cur >> 31) != 0);
