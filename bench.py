@@ -316,7 +316,7 @@ def gather_h_scalars(env, circ, split):
     import torch
     from zkpoa_amd.sharding import shard_range
     n, world, rank = circ.n, env.world, env.rank
-    if world == 1:
+    if world == 1 and not env.multi:      # (ZKPOA_BENCH_FORCE_DIST=1: one rank still goes through the collective)
         return circ.h_scalars()
     rows = -(-n // world)
     mine = np.zeros((rows, 4), dtype=np.uint64)

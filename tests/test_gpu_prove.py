@@ -815,6 +815,30 @@ def test_multi_process_sharded_prove_rehearsal(nproc, extra):
     assert line["n_ranks_seen"] == nproc
 
 
+def test_bench_collectives_over_rccl_with_one_rank():
+    """The N > 1 code path of bench.py over the REAL RCCL backend, as far as one GPU allows: ZKPOA_BENCH_FORCE_DIST=1
+    initialises the nccl process group with a single rank and sends the MSM partials, the timing reduction, the pass /
+    fail agreement and the gathered H scalars (pi_c check) through its collectives."""
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for workload in ("prove_2p16", "msm_g1_2p16"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, ZKPOA_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+                   WORLD_SIZE="1", LOCAL_RANK="0")
+        rc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                             "--workload", workload, "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                            timeout=600, cwd=root)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        line = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["collectives"] == "nccl" and line["n_ranks_seen"] == 1
+        if workload.startswith("prove"):
+            assert "pi_c" in line["config"]["checked"]
+
+
 # ---- ADVICE r01: failure paths that used to be silent or sticky ---------------------------------------------------
 def test_server_death_mid_request_still_yields_the_proof(zk, tmp_path):
     """The resident server dies with a request in hand (ZKPOA_SERVER_TEST_CRASH): the client proves in its own
