@@ -37,6 +37,16 @@ struct RankBarrier {   // host barrier of the rank threads (C++17: no std::barri
       cv.wait(lk, [&] { return gen != generation; });
     }
   }
+  // `missing` participants will never arrive (their threads could not be started): the others must not wait for them
+  void abandon(unsigned missing) {
+    std::unique_lock<std::mutex> lk(m);
+    n -= missing < n ? missing : n;
+    if (n && waiting >= n) {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+    }
+  }
 };
 
 struct DeviceSet {
@@ -299,8 +309,8 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
   std::atomic<bool> failed{false};
   std::vector<std::exception_ptr> errs(G);
   std::vector<std::thread> th;
-  for (size_t g = 0; g < G; g++)
-    th.emplace_back([&, g] {
+  th.reserve(G);
+  auto rank_main = [&](size_t g) {
       // Phases separated by barriers; a rank that fails keeps arriving at the barriers so that nobody waits for ever.
       auto phase = [&](const std::function<void()>& fn) {
         if (failed.load()) return;
@@ -341,8 +351,20 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       phase([&] { prove_partials(ctx, zk, parts[g].data()); });
       // a rank must not start the next proof's pushes into a peer that still reads this proof's buffers
       phase([&] { ZK_HIP(hipStreamSynchronize(st)); });
-    });
+  };
+  std::exception_ptr spawn_err;
+  for (size_t g = 0; g < G; g++) {
+    try {
+      th.emplace_back(rank_main, g);
+    } catch (...) {   // out of threads: the ranks that did start must not wait at the barriers for the ones that did not
+      spawn_err = std::current_exception();
+      failed.store(true);
+      bar.abandon((unsigned)(G - g));
+      break;
+    }
+  }
   for (auto& t : th) t.join();
+  if (spawn_err) std::rethrow_exception(spawn_err);
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
   // "all-reduce of the partial sums": five tiny host-side group sums (G points each)
