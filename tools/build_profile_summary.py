@@ -78,7 +78,7 @@ for tag, name in (("msm20", "msm_g1_2p20"), ("msm20fb", "msm_g1_2p20_fixed_base"
 ONCE = ("msm_table_", "gen_bases", "query_", "abc_count", "abc_scatter", "abc_long_list", "fr_pow_table", "ntt_direct_table",
         "to_affine", "strided_copy", "msm_density")
 STREAMING = ("digits", "sort_", "scan_", "piece_", "ntt_pass", "abc_join", "range_check", "gather32", "gather_bc32")
-for tag, name in (("prove21", "prove_2p21"), ("prove26", "prove_2p26")):
+for tag, name in (("prove21", "prove_2p21"), ("prove25", "prove_2p25"), ("prove26", "prove_2p26")):
     if not glob.glob(os.path.join(SRC, "pmc_%s_FETCH_SIZE" % tag)):
         continue
     f, w = summarize(tag, "FETCH_SIZE"), summarize(tag, "WRITE_SIZE")

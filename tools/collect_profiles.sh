@@ -48,6 +48,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   # says how many proofs the process ran (config.proofs_run_in_process)
   $P -d $O/pmc_prove21_$c -- $B --workload prove_2p21 --steps 4 --warmup 1 --serial --no-cpu-baseline > $O/pmc_prove21_$c.log 2>&1
   $P -d $O/pmc_prove26_$c -- $B --workload prove_2p26 --steps 1 --warmup 0 --serial --no-cpu-baseline > $O/pmc_prove26_$c.log 2>&1
+  $P -d $O/pmc_prove25_$c -- $B --workload prove_2p25 --steps 1 --warmup 0 --serial --no-cpu-baseline > $O/pmc_prove25_$c.log 2>&1
 done
 echo "pmc done"
 fi
