@@ -346,33 +346,14 @@ def gather_h_scalars(env, circ, split):
     return P
 
 
-def binfile(magic, version, sections):
-    """iden3 binfile container from (id, bytes-like) pairs, as one bytes object."""
-    out = [magic, int(version).to_bytes(4, "little"), len(sections).to_bytes(4, "little")]
-    for sid, payload in sections:
-        out += [int(sid).to_bytes(4, "little"), len(payload).to_bytes(8, "little"), payload]
-    return b"".join(out)
-
-
 def cpu_prove_baseline(env, circ, gpu_points):
     """The same proof on the host: the synthetic key's sections are copied out of HBM into a .zkey image and the C
     oracle (oracle/c: orc_prove -- buildABC, 6 NTTs, joinABC, the five Pippenger MSMs, assembly) proves it on the
     job's cores with r = s = 0. Its 256 proof bytes must equal the GPU's: a whole-proof oracle parity at this shape."""
     from oracle import c_oracle as co
     cores = host_cores()
-    m, npub = circ.m, circ.n_public
-    hp = circ.header_points                            # alpha1 beta1 beta2 delta1 delta2
-    g2gen = hp[128:256]                                # gamma2: any G2 point (the prover never reads it)
-    sec2 = (b"".join([(32).to_bytes(4, "little"), Q_MOD.to_bytes(32, "little"), (32).to_bytes(4, "little"),
-                      R_MOD.to_bytes(32, "little"), m.to_bytes(4, "little"), npub.to_bytes(4, "little"),
-                      circ.n.to_bytes(4, "little")]) + hp[0:64] + hp[64:128] + hp[128:256] + g2gen + hp[256:320] + hp[320:448])
-    dev_bytes = lambda t, count, size: t[:count * size].cpu().numpy().tobytes()
-    zkey = binfile(b"zkey", 1, [
-        (1, (1).to_bytes(4, "little")), (2, sec2), (3, bytes(64 * (npub + 1))), (4, circ.coeff_section_bytes()),
-        (5, dev_bytes(circ.d_A, m, 64)), (6, dev_bytes(circ.d_B1, m, 64)), (7, dev_bytes(circ.d_B2, m, 128)),
-        (8, dev_bytes(circ.d_C, m - npub - 1, 64)), (9, dev_bytes(circ.d_H, circ.n, 64))])
-    wtns = binfile(b"wtns", 2, [(1, (32).to_bytes(4, "little") + R_MOD.to_bytes(32, "little") + m.to_bytes(4, "little")),
-                                (2, circ.witness_bytes())])
+    npub = circ.n_public
+    zkey, wtns = circ.zkey_image(), circ.wtns_image()
     tc = time.perf_counter()
     ref, _ = co.prove(zkey, wtns, 0, 0, cores, n_public=npub)
     tcpu = time.perf_counter() - tc

@@ -360,6 +360,37 @@ def test_prover_cli_several_ranks_mid_size_server_and_errors(zk, tmp_path, mid_c
         assert rc.returncode != 0 and "ZKPOA_DEVICES" in rc.stderr and not (tmp_path / "bad.json").exists(), (bad, rc.stderr)
 
 
+@pytest.mark.parametrize("witness_like", [False, True])
+def test_prover_cli_several_ranks_2p16_vs_c_oracle(ctx, zk, tmp_path, witness_like):
+    """A 2^16-constraint key with 60,000 wires written as a real .zkey / .wtns pair (the synthetic circuit's sections
+    copied out of HBM): the `prover` executable on 1, 2, 4 and 8 ranks (block-cyclic sections 5-8 in blocks of 2^9 - 2^12
+    wires, cyclic section 9, split chain) must write the same proof.json, and its points must equal the C oracle's
+    orc_prove on the same files -- the multi-GPU drop-in against the oracle at a size where every rank holds several
+    blocks and the hot bucket of a witness-like distribution spans them."""
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    circ = SyntheticCircuit(zk, ctx, 16, 60000, n_public=2, seed=77, witness_like=witness_like)
+    try:
+        zkey, wtns = circ.zkey_image(), circ.wtns_image()
+    finally:
+        circ.close()
+    (tmp_path / "circuit_final.zkey").write_bytes(zkey)
+    (tmp_path / "witness.wtns").write_bytes(wtns)
+    r_, s_ = 1234567, 7654321
+    want_pts, want_pub = co.prove(zkey, wtns, r_, s_, 8, n_public=2)
+    want = zk.proof_to_json(want_pts, "rapidsnark")
+    base = dict(os.environ, ZKPOA_R=str(r_), ZKPOA_S=str(s_), ZKPOA_VERBOSE="1", ZKPOA_SELFCHECK="0")   # no valid vkey inside
+    base.pop("ZKPOA_SERVER", None)
+    for devices in ("0", "0,0", "0,0,0,0", "0,0,0,0,0,0,0,0"):
+        out = "proof_%d.json" % len(devices)
+        rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", out, "public.json"],
+                            env=dict(base, ZKPOA_DEVICES=devices), capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert rc.returncode == 0, rc.stderr
+        assert (tmp_path / out).read_text() == want, devices
+        assert (tmp_path / "public.json").read_text() == zk.public_to_json(want_pub, "rapidsnark")
+        if "," in devices:
+            assert "H-scalar chain split" in rc.stderr and "block-cyclic" in rc.stderr
+
+
 def test_prover_cli_server_mode(zk, tmp_path):
     """ZKPOA_SERVER: same argv, exit codes and output bytes, but the proofs come from a resident prover
     process that keeps the key in HBM between calls (second call = cache hit)."""

@@ -220,6 +220,37 @@ class SyntheticCircuit:
     def witness_bytes(self):
         return self.w_limbs.tobytes()
 
+    @staticmethod
+    def _binfile(magic, version, sections):
+        """iden3 binfile container from (id, bytes-like) pairs, as one bytes object."""
+        out = [magic, int(version).to_bytes(4, "little"), len(sections).to_bytes(4, "little")]
+        for sid, payload in sections:
+            out += [int(sid).to_bytes(4, "little"), len(payload).to_bytes(8, "little"), payload]
+        return b"".join(out)
+
+    def zkey_image(self):
+        """The whole (unsharded) synthetic key as a .zkey file image: the sections are copied out of HBM, gamma2 is
+        set to beta2 (the prover never reads it) and section 3 (IC) to points at infinity, so the image has no valid
+        verification key -- it is for provers (this one through its file entry points, the C oracle), not verifiers."""
+        if self.shard is not None:
+            raise RuntimeError("zkey_image needs the unsharded circuit")
+        m, npub, hp = self.m, self.n_public, self.header_points          # alpha1 beta1 beta2 delta1 delta2
+        sec2 = (b"".join([(32).to_bytes(4, "little"), Q_MOD.to_bytes(32, "little"), (32).to_bytes(4, "little"),
+                          R_MOD.to_bytes(32, "little"), m.to_bytes(4, "little"), npub.to_bytes(4, "little"),
+                          self.n.to_bytes(4, "little")]) + hp[0:64] + hp[64:128] + hp[128:256] + hp[128:256] +
+                hp[256:320] + hp[320:448])
+        dev = lambda t, count, size: t[:count * size].cpu().numpy().tobytes()
+        return self._binfile(b"zkey", 1, [
+            (1, (1).to_bytes(4, "little")), (2, sec2), (3, bytes(64 * (npub + 1))), (4, self.coeff_section_bytes()),
+            (5, dev(self.d_A, m, 64)), (6, dev(self.d_B1, m, 64)), (7, dev(self.d_B2, m, 128)),
+            (8, dev(self.d_C, m - npub - 1, 64)), (9, dev(self.d_H, self.n, 64))])
+
+    def wtns_image(self):
+        """The witness as a .wtns file image."""
+        return self._binfile(b"wtns", 2, [
+            (1, (32).to_bytes(4, "little") + R_MOD.to_bytes(32, "little") + self.m.to_bytes(4, "little")),
+            (2, self.witness_bytes())])
+
     def prove(self, r=0, s=0):
         return self.ctx.prove_device(self.key, self.d_witness.data_ptr(), r, s)
 
