@@ -70,6 +70,20 @@ def test_reference_script_reaches_the_prover_and_fails_loudly_without_gpu(zk, tm
     assert not [f for f in os.listdir(tmp_path / "batch_0") if ".tmp." in f]           # no partial outputs either
 
 
+def test_reference_script_with_a_device_list_in_the_environment(zk, tmp_path):
+    """The multi-GPU drop-in is configured by environment only (ZKPOA_DEVICES), so it passes through the unchanged
+    script like ZKPOA_R / ZKPOA_S do: without a GPU the same loud failure, exit code and ERR trap, no partial outputs."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: see the gpu-marked variant")
+    g, env, argv = _layout(tmp_path, zk)
+    rc = subprocess.run(argv, env=dict(env, ZKPOA_DEVICES="0,1,2,3"), capture_output=True, text=True, timeout=120)
+    out = rc.stdout + rc.stderr
+    assert rc.returncode != 0 and "no HIP device" in rc.stderr and "ERROR GENERATING PROOF USING RAPIDSNARK" in out
+    assert not (tmp_path / "batch_0" / "proof.json").exists()
+    assert not [f for f in os.listdir(tmp_path / "batch_0") if ".tmp." in f]
+
+
 def test_reference_script_rejects_a_prover_with_another_basename(zk, tmp_path):
     """g16_prove.sh:195-199: the binary must be called `prover` -- which is why ours is."""
     g, env, argv = _layout(tmp_path, zk)
@@ -82,9 +96,13 @@ def test_reference_script_rejects_a_prover_with_another_basename(zk, tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_script_end_to_end_on_gpu(zk, tmp_path):
-    """Same run where both the reference and a GPU exist: golden proof bytes through the unchanged script."""
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0,0"])
+def test_reference_script_end_to_end_on_gpu(zk, tmp_path, devices):
+    """Same run where both the reference and a GPU exist: golden proof bytes through the unchanged script -- on one
+    device, and with one proof over 2 / 4 ranks (ZKPOA_DEVICES; ranks share the device on a one-GPU box)."""
     g, env, argv = _layout(tmp_path, zk)
+    if devices:
+        env = dict(env, ZKPOA_DEVICES=devices)
     rc = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=300)
     assert rc.returncode == 0, rc.stdout + rc.stderr
     assert "DONE G16 PROVE" in rc.stdout
