@@ -182,3 +182,34 @@ def test_prover_server_failure_paths_without_gpu(zk, tmp_path):
         quiet.close()
     finally:
         subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
+def test_automatic_gpu_choice_of_the_multi_gpu_drop_in(zk):
+    """csrc/multi_device.hip.h auto_pick_devices (through a test hook; no GPU needed): what `prover` does on a node with
+    several GPUs when neither ZKPOA_DEVICES nor ZKPOA_DEVICE is set -- the policy behind "full_workflow.sh unchanged":
+    small keys take ONE free GPU, the search starting at pid mod #GPUs (parallel batch jobs spread out); keys of
+    2^24 constraints or more take every free GPU, cut to 2 / 4 / 8; nothing free -> queue behind GPU pid mod #GPUs."""
+    import ctypes
+    L = zk.lib()
+    f = L.zkpoa_test_auto_pick_devices
+    f.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_ulong, ctypes.c_uint, ctypes.POINTER(ctypes.c_int)]
+
+    def pick(count, power, pid, busy=0, min_power=24):
+        out = (ctypes.c_int * 8)()
+        n = f(count, power, min_power, pid, busy, out)
+        return list(out[:n])
+    # layer-one / layer-two sized keys: one GPU each, different processes start at different GPUs, busy ones are skipped
+    assert pick(8, 21, pid=1000) == [0] and pick(8, 21, pid=1003) == [3] and pick(8, 23, pid=1007) == [7]
+    assert pick(8, 21, pid=1003, busy=0b00001000) == [4]
+    assert pick(8, 21, pid=1007, busy=0b10000000) == [0]                       # wraps around
+    assert pick(4, 21, pid=6, busy=0b1111) == [2]                              # all taken: wait for pid mod count
+    assert sorted({tuple(pick(8, 21, pid=p)) for p in range(100, 108)}) == [(d,) for d in range(8)]
+    # a layer-three sized key (2^26) alone on the node: all 8; with some GPUs busy: the free ones, cut to a power of two
+    assert pick(8, 26, pid=5) == list(range(8))
+    assert pick(8, 26, pid=5, busy=0b00000001) == [1, 2, 3, 4]                 # 7 free -> 4
+    assert pick(8, 26, pid=5, busy=0b11110000) == [0, 1, 2, 3]
+    assert pick(8, 26, pid=5, busy=0b11111010) == [0, 2]
+    assert pick(8, 26, pid=5, busy=0b11111110) == [0]
+    assert pick(8, 26, pid=13, busy=0b11111111) == [5]                         # nothing free: queue behind pid mod 8
+    assert pick(2, 25, pid=9) == [0, 1] and pick(3, 25, pid=9) == [0, 1] and pick(16, 26, pid=1) == list(range(8))
+    assert pick(8, 23, pid=2, min_power=23) == list(range(8))                  # ZKPOA_MULTI_MIN_POWER

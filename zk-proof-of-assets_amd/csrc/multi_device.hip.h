@@ -81,6 +81,32 @@ int try_lock_gpu(int dev, bool block) {
   return fd;
 }
 
+// The automatic choice, free of HIP and of the file system so that it can be tested without GPUs
+// (zkpoa_test_auto_pick_devices): a key with domain >= 2^min_power wants every GPU (at most 8), a smaller one wants one;
+// GPUs are tried in order -- for a single-GPU proof starting at pid mod count, so that concurrent batch jobs start at
+// different GPUs -- and taken when `lock(d, false)` succeeds; nothing free: wait for GPU pid mod count (`lock(d, true)`);
+// the list is cut to a power of two (`release(keep)` gives the surplus locks back, last taken first).
+template <class Lock, class Release>
+std::vector<int> auto_pick_devices(int count, uint32_t power, uint32_t min_power, unsigned long pid, Lock lock, Release release) {
+  std::vector<int> ids;
+  const int want = power >= min_power ? (count > 8 ? 8 : count) : 1;
+  const int first = want == 1 ? (int)(pid % (unsigned long)count) : 0;
+  for (int k = 0; k < count && (int)ids.size() < want; k++) {
+    const int d = (first + k) % count;
+    if (lock(d, false)) ids.push_back(d);
+  }
+  if (ids.empty()) {
+    const int d = (int)(pid % (unsigned long)count);
+    (void)lock(d, true);
+    ids.push_back(d);
+  }
+  size_t keep = 1;
+  while (keep * 2 <= ids.size()) keep *= 2;   // the split chain wants 2, 4 or 8 ranks
+  ids.resize(keep);
+  release(keep);
+  return ids;
+}
+
 // the device list for this process; `power` = log2 of the first key's domain (automatic selection only)
 void select_devices(DeviceSet& ds, uint32_t power) {
   int count = 0;
@@ -116,29 +142,18 @@ void select_devices(DeviceSet& ds, uint32_t power) {
   ds.automatic = true;
   uint32_t min_power = 24;
   if (const char* e = getenv("ZKPOA_MULTI_MIN_POWER")) min_power = (uint32_t)atoi(e);
-  const int want = power >= min_power ? (count > 8 ? 8 : count) : 1;
-  const int first = want == 1 ? (int)((unsigned long)getpid() % (unsigned long)count) : 0;   // batch jobs start at different GPUs
-  for (int k = 0; k < count && (int)ds.ids.size() < want; k++) {
-    const int d = (first + k) % count;
-    int fd = try_lock_gpu(d, false);
-    if (fd >= 0) {
-      ds.ids.push_back(d);
-      ds.lock_fds.push_back(fd);
+  std::vector<int> fds;
+  ds.ids = auto_pick_devices(count, power, min_power, (unsigned long)getpid(), [&](int d, bool block) {
+    int fd = try_lock_gpu(d, block);
+    if (fd >= 0) fds.push_back(fd);
+    return fd >= 0 || block;   // a blocking attempt that could not even open its lock file still proceeds on that GPU
+  }, [&](size_t keep) {
+    while (fds.size() > keep) {
+      close(fds.back());
+      fds.pop_back();
     }
-  }
-  if (ds.ids.empty()) {   // every GPU is taken: queue behind one of them
-    const int d = (int)((unsigned long)getpid() % (unsigned long)count);
-    int fd = try_lock_gpu(d, true);
-    ds.ids.push_back(d);
-    if (fd >= 0) ds.lock_fds.push_back(fd);
-  }
-  size_t keep = 1;
-  while (keep * 2 <= ds.ids.size()) keep *= 2;   // the split chain wants 2, 4 or 8 ranks
-  while (ds.ids.size() > keep) {
-    ds.ids.pop_back();
-    close(ds.lock_fds.back());
-    ds.lock_fds.pop_back();
-  }
+  });
+  ds.lock_fds = fds;
 }
 
 // Contexts of the process, created once (first prove decides the device list). Ranks come up in parallel: a context

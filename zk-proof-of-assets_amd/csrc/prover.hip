@@ -2268,6 +2268,28 @@ extern "C" int zkpoa_h_scalars(zkpoa_context* ctx, const void* coeffs, unsigned 
   return PROVER_OK;
 }
 
+// Test hook (not in the header): the automatic GPU choice of the multi-GPU drop-in for a node of `count` GPUs of which
+// those in busy_mask are locked by other provers. out <- the chosen devices; returns how many.
+extern "C" int zkpoa_test_auto_pick_devices(int count, unsigned power, unsigned min_power, unsigned long pid,
+                                            unsigned busy_mask, int out[8]) {
+  if (count <= 0 || count > 32 || !out) return -1;
+  unsigned taken = 0;
+  std::vector<int> order;
+  std::vector<int> ids = auto_pick_devices(count, power, min_power, pid, [&](int d, bool block) {
+    if (!block && ((busy_mask | taken) >> d) & 1u) return false;
+    taken |= 1u << d;
+    order.push_back(d);
+    return true;
+  }, [&](size_t keep) {
+    while (order.size() > keep) {
+      taken &= ~(1u << order.back());
+      order.pop_back();
+    }
+  });
+  for (size_t i = 0; i < ids.size() && i < 8; i++) out[i] = ids[i];
+  return (int)ids.size();
+}
+
 extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer,
                               unsigned long wtns_size, char* proof_buffer, unsigned long* proof_size,
                               char* public_buffer, unsigned long* public_size, char* error_msg,
