@@ -11,8 +11,9 @@ all-gathered over RCCL and summed on every rank -- SURVEY.md 8e).
 Prints ONE JSON line on rank 0. BASELINE.json's metric is "Groth16 proofs/sec + G1-MSM pts/s at 2^20 / 2^26", so
 with N = 1 and the default workload the same line carries, under "also", the other shapes of that metric measured
 in the same process: the 2^26 MSM, the 2^20 MSM in fixed-base form, and full proves at the layer_one(2 sigs)
-2^21 shape and the synthetic layer_one(128 sigs) 2^26 shape -- each with its own step count, roofline object and
-correctness check (pi_c included). `value` is always the headline workload alone.
+2^21 shape, the layer_two(2, 12) 2^25 shape, the synthetic layer_one(128 sigs) 2^26 shape and the layer_three(2)
+2^26 / 13-public shape (prove_2p26_l3) -- each with its own step count, roofline object and correctness check (pi_c
+included). With --gpus N > 1 the default workload is ONE 2^26 proof over the N GPUs (strong scaling). `value` is always the headline workload alone.
 """
 import argparse
 import json
@@ -102,7 +103,17 @@ PROVE_SHAPES = {
     21: (2083343, 1, "layer_one(2 sigs) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:17-23"),
     25: (21356921, 2, "layer_two(2,12) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:33-39"),
     26: (61197000, 1, "synthetic layer_one(128 sigs) shape, tests/old/128_sigs/benchmarks.txt:4-10"),
+    "26_l3": (52367163, 13, "layer_three(2) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:49-55"),
 }
+
+
+def prove_shape(spec):
+    """'21' | '25' | '26' | '26_l3' (workload prove_2p<spec>) -> (log2 domain, wires, public signals, description)."""
+    key = int(spec) if str(spec).isdigit() else str(spec)
+    if key not in PROVE_SHAPES:
+        raise SystemExit("unknown prove workload prove_2p%s (known: %s)" % (spec, ", ".join(str(k) for k in PROVE_SHAPES)))
+    m, n_pub, what = PROVE_SHAPES[key]
+    return int(str(spec).split("_")[0]), m, n_pub, what
 
 
 class Env:
@@ -376,7 +387,8 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
     from zkpoa_amd import sharding
     from zkpoa_amd.synthetic import SyntheticCircuit
     zk, ctx, dist, args = env.zk, env.ctx, env.dist, env.args
-    m, n_pub, what = PROVE_SHAPES[k]
+    spec = k
+    k, m, n_pub, what = prove_shape(spec)
     world, rank = env.world, env.rank
     # N > 1: ONE proof sharded over the N GPUs (strong scaling): same circuit on every rank, each rank
     # owns index range rank/N of the five MSMs; partial points are all-gathered over RCCL and summed.
@@ -485,7 +497,7 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
         # SURVEY.md 8d full-prove formula
         alg = 96 * (3 * m - n_pub - 1) + 160 * m + 96 * n + 6 * 64 * n + 76 * ncoef + 96 * n + 128 * n
         sec = elapsed / steps
-        traffic, tsrc = pmc_traffic("prove_2p%d" % k, "per_proof") if world == 1 else (None, None)
+        traffic, tsrc = pmc_traffic("prove_2p%s" % spec, "per_proof") if world == 1 else (None, None)
         roof = {"bound": "hbm", "kernel": "whole prove (5 MSMs + H chain)",
                 "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
@@ -678,7 +690,7 @@ def main():
         if os.environ.get("ZKPOA_MSM_K0"):       # experiments only: force the level-0 piece length
             env.ctx.set_option("msm_k0", int(os.environ["ZKPOA_MSM_K0"]))
         if args.workload.startswith("prove_2p"):
-            line = prove_leg(env, int(args.workload[len("prove_2p"):]), args.steps, args.warmup,
+            line = prove_leg(env, args.workload[len("prove_2p"):], args.steps, args.warmup,
                              precompute=not args.no_precompute, serial=args.serial,
                              cpu_baseline=(world == 1 and not args.no_cpu_baseline and args.workload == "prove_2p21"))
         elif args.workload.startswith("merkle_"):
@@ -700,6 +712,7 @@ def main():
                     ("prove_2p21", lambda: prove_leg(env, 21, 20, 3, cpu_baseline=not args.no_cpu_baseline)),
                     ("prove_2p25", lambda: prove_leg(env, 25, 4, 1)),
                     ("prove_2p26", lambda: prove_leg(env, 26, 3, 1)),
+                    ("prove_2p26_l3", lambda: prove_leg(env, "26_l3", 3, 1)),
                     ("merkle_10M", lambda: merkle_leg(env, 10_000_000, 3, 1))):
                 t0 = time.perf_counter()
                 leg = fn()
