@@ -357,6 +357,47 @@ def gather_h_scalars(env, circ, split):
     return P
 
 
+def probe_reference_provers(zkey, wtns):
+    """if the box happens to have the reference's own provers -- `snarkjs` (with node >= 16) or
+    a rapidsnark `prover` binary (on PATH under another directory than ours, or named by $RAPIDSNARK_REF_PATH) -- time
+    them on the same key and witness. Never installs anything; on the build pool neither exists and this reports so."""
+    import shutil
+    import subprocess
+    import tempfile
+    ours = os.path.realpath(os.path.join(ROOT, "zk-proof-of-assets_amd", "prover"))
+    cands = {}
+    sj = shutil.which("snarkjs")
+    node = shutil.which("node")
+    if sj and node:
+        try:
+            major = int(subprocess.run([node, "--version"], capture_output=True, text=True, timeout=10).stdout.strip().lstrip("v").split(".")[0])
+        except (ValueError, OSError, subprocess.SubprocessError):
+            major = 0
+        if major >= 16:
+            cands["snarkjs"] = [sj, "groth16", "prove"]
+    rs = os.environ.get("RAPIDSNARK_REF_PATH") or shutil.which("prover")
+    if rs and os.path.realpath(rs) != ours and os.access(rs, os.X_OK):
+        cands["rapidsnark"] = [rs]
+    out = {"probed": "snarkjs + node >= 16 on PATH; a rapidsnark `prover` on PATH or $RAPIDSNARK_REF_PATH", "found": sorted(cands)}
+    if not cands:
+        return out
+    with tempfile.TemporaryDirectory() as d:
+        zp, wp = os.path.join(d, "c.zkey"), os.path.join(d, "w.wtns")
+        with open(zp, "wb") as f:
+            f.write(zkey)
+        with open(wp, "wb") as f:
+            f.write(wtns)
+        for name, argv in cands.items():
+            t0 = time.perf_counter()
+            try:
+                rc = subprocess.run(argv + [zp, wp, os.path.join(d, name + "_proof.json"), os.path.join(d, name + "_public.json")],
+                                    capture_output=True, text=True, timeout=600)
+                out[name] = {"seconds": time.perf_counter() - t0, "rc": rc.returncode}
+            except (OSError, subprocess.SubprocessError) as e:
+                out[name] = {"error": str(e)[:200]}
+    return out
+
+
 def cpu_prove_baseline(env, circ, gpu_points):
     """The same proof on the host: the synthetic key's sections are copied out of HBM into a .zkey image and the C
     oracle (oracle/c: orc_prove -- buildABC, 6 NTTs, joinABC, the five Pippenger MSMs, assembly) proves it on the
@@ -370,7 +411,8 @@ def cpu_prove_baseline(env, circ, gpu_points):
     tcpu = time.perf_counter() - tc
     if ref != gpu_points:
         raise BenchError("GPU proof and C-oracle proof differ (r = s = 0)")
-    return {"value": 1.0 / tcpu, "unit": "proofs/s", "cores": cores, "nproc": box_cores(), "kind": "port",
+    probe = probe_reference_provers(zkey, wtns)
+    return {"reference_provers": probe, "value": 1.0 / tcpu, "unit": "proofs/s", "cores": cores, "nproc": box_cores(), "kind": "port",
             "sample": "ONE complete proof of the same key and witness (%.2f GB zkey image copied out of HBM), r = s = 0; C "
                       "oracle orc_prove (oracle/c: single-threaded buildABC + NTT chain, then five Pippenger MSMs threaded "
                       "over (window, chunk) tasks) on %d threads = this job's share of the box (nproc = %d); proof bytes equal "
