@@ -584,6 +584,8 @@ template <> struct AccumWaves<Fq2> { static constexpr int N = 2; };
 // level 0: items are sorted point indices; piece j of bucket b covers entries
 // [off0[b] + j*K0, min(off0[b] + cnt0[b], +K0)). Threads take pieces in `order` (longest first).
 template <class F>
+constexpr bool kAccumPrefetch = FieldBytes<F>::N <= 32;
+template <class F>
 static __global__ __launch_bounds__(256, AccumWaves<F>::N) void msm_accum0_kernel(const void* __restrict__ bases,
                                                          const uint32_t* __restrict__ sorted,
                                                          const uint32_t* __restrict__ cnt0,
@@ -612,8 +614,11 @@ static __global__ __launch_bounds__(256, AccumWaves<F>::N) void msm_accum0_kerne
   // is 256-byte aligned and padded (Arena::take).
   const uint4* sorted4 = reinterpret_cast<const uint4*>(sorted);
   uint32_t blk = start >> 2;
-  uint4 cache = sorted4[blk];
+  uint4 cache = FieldBytes<F>::N > 32 ? make_uint4(0, 0, 0, 0) : sorted4[blk];
   auto entry = [&](uint32_t k) -> uint32_t {
+    // G2: the accumulation already needs every one of the 256 VGPRs two waves per SIMD leave it; the five registers
+    // of the block cache would go to scratch, and a G2 addition is long enough for the line to be worth re-reading
+    if (FieldBytes<F>::N > 32) return sorted[k];
     if ((k >> 2) != blk) {
       blk = k >> 2;
       cache = sorted4[blk];
@@ -621,16 +626,24 @@ static __global__ __launch_bounds__(256, AccumWaves<F>::N) void msm_accum0_kerne
     const uint32_t i = k & 3u;
     return i == 0u ? cache.x : (i == 1u ? cache.y : (i == 2u ? cache.z : cache.w));
   };
-  uint32_t e = entry(start);
-  Affine<F> p = load_affine<F>(bases, e & 0x7fffffffu);
-  for (uint32_t k = start; k < end; k++) {
-    uint32_t e_cur = e;
-    Affine<F> p_cur = p;
-    if (k + 1 < end) {  // prefetch the next base under this addition
-      e = entry(k + 1);
-      p = load_affine<F>(bases, e & 0x7fffffffu);
+  if (kAccumPrefetch<F>) {
+    uint32_t e = entry(start);
+    Affine<F> p = load_affine<F>(bases, e & 0x7fffffffu);
+    for (uint32_t k = start; k < end; k++) {
+      uint32_t e_cur = e;
+      Affine<F> p_cur = p;
+      if (k + 1 < end) {  // prefetch the next base under this addition
+        e = entry(k + 1);
+        p = load_affine<F>(bases, e & 0x7fffffffu);
+      }
+      xyzz_add_affine(acc, p_cur, (e_cur >> 31) != 0);
     }
-    xyzz_add_affine(acc, p_cur, (e_cur >> 31) != 0);
+  } else {   // G2: no room for a second 128-byte point in registers; the other wave of the SIMD covers the gather
+    for (uint32_t k = start; k < end; k++) {
+      const uint32_t e = entry(k);
+      const Affine<F> p = load_affine<F>(bases, e & 0x7fffffffu);
+      xyzz_add_affine(acc, p, (e >> 31) != 0);
+    }
   }
   uint32_t pieces = (cnt + K0 - 1) / K0;
   if (pieces == 1) store_xyzz(buckets, b, acc);
