@@ -66,18 +66,25 @@ bool devices_ready() {
 
 std::string gpu_lock_dir() { return "/tmp/zkpoa-" + std::to_string((long)getuid()); }
 
+// The lock directory lives in /tmp, so it must be a real directory of this user that nobody else can write to (not a
+// symlink, not something another user created first); otherwise no lock is taken and the caller falls back to its
+// pid-based choice. Lock files are opened without following symlinks and are never written to.
+bool gpu_lock_dir_ok(const std::string& dir) {
+  if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
+  struct stat sb;
+  return lstat(dir.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode) && sb.st_uid == getuid() && (sb.st_mode & 0022) == 0;
+}
+
 int try_lock_gpu(int dev, bool block) {
   const std::string dir = gpu_lock_dir();
-  (void)mkdir(dir.c_str(), 0700);
+  if (!gpu_lock_dir_ok(dir)) return -1;
   const std::string path = dir + "/gpu" + std::to_string(dev) + ".lock";
-  int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+  int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
   if (fd < 0) return -1;
   if (flock(fd, LOCK_EX | (block ? 0 : LOCK_NB)) != 0) {
     close(fd);
     return -1;
   }
-  const std::string pid = std::to_string((long)getpid()) + "\n";
-  if (ftruncate(fd, 0) == 0) (void)!pwrite(fd, pid.data(), pid.size(), 0);
   return fd;
 }
 

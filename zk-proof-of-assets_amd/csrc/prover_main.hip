@@ -130,6 +130,14 @@ static void log_fault(const char* what, const std::string& detail, const char* z
   const std::string path = fault_log_path();
   const std::string dir = path.substr(0, path.rfind('/'));
   (void)mkdir(dir.c_str(), 0700);
+  {   // /tmp is shared: only a real directory of this user that others cannot write to, and never through a symlink
+    struct stat sb;
+    if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & 0022) != 0) {
+      fprintf(stderr, "zkpoa: GPU-side failure (%s: %s); %s is not a private directory of this user, nothing logged\n", what,
+              detail.c_str(), dir.c_str());
+      return;
+    }
+  }
   char when[64] = {0};
   time_t now = time(nullptr);
   struct tm tmv;
@@ -139,7 +147,7 @@ static void log_fault(const char* what, const std::string& detail, const char* z
                      " | zkey " + (zkey ? abs_path(zkey) : std::string("-")) + "\n";
   for (char& c : line)
     if ((c == '\n' || c == '\r') && &c != &line[line.size() - 1]) c = ' ';
-  int fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND | O_CLOEXEC, 0600);
+  int fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND | O_CLOEXEC | O_NOFOLLOW, 0600);
   if (fd >= 0) {
     (void)!write(fd, line.data(), line.size());   // O_APPEND: one write per line, concurrent provers do not interleave
     close(fd);
