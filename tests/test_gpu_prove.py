@@ -389,6 +389,12 @@ def test_prover_cli_several_ranks_2p16_vs_c_oracle(ctx, zk, tmp_path, witness_li
         assert (tmp_path / "public.json").read_text() == zk.public_to_json(want_pub, "rapidsnark")
         if "," in devices:
             assert "H-scalar chain split" in rc.stderr and "block-cyclic" in rc.stderr
+    # the exchanges as hipMemcpyPeerAsync copies instead of the peer-write kernel (what a pair without a direct path gets)
+    rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof_copy.json", "public.json"],
+                        env=dict(base, ZKPOA_DEVICES="0,0,0,0", ZKPOA_EXCHANGE="copy"), capture_output=True, text=True,
+                        cwd=tmp_path, timeout=300)
+    assert rc.returncode == 0, rc.stderr
+    assert (tmp_path / "proof_copy.json").read_text() == want
 
 
 def test_prover_cli_server_mode(zk, tmp_path):

@@ -276,6 +276,23 @@ static __global__ __launch_bounds__(256) void gather32_kernel(const uint4* __res
   out[q] = values[(uint64_t)idx[q >> 1] * 2u + (q & 1u)];
 }
 
+// One exchange of the split chain as ONE kernel (csrc/multi_device.hip.h): chunk h of this rank's send buffer goes
+// straight into rank h's receive buffer through its peer-mapped address -- every xGMI link of the GPU carries its own
+// pair at the same time (G copies enqueued on one stream would run one after the other, one link at a time), and the
+// stores sit on the stage's own stream, so no extra ordering is needed. The walk over the peers starts at the rank's own
+// slot so that at any moment the ranks aim at different peers. dst.p[h] = where rank h wants THIS rank's chunk.
+struct XchgDst {
+  char* p[8];
+};
+static __global__ __launch_bounds__(256) void xchg_push_kernel(const uint4* __restrict__ src, XchgDst dst, uint64_t chunk16,
+                                                               uint32_t G, uint32_t self) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= chunk16 * G) return;
+  const uint32_t h = (self + (uint32_t)(i / chunk16)) % G;
+  const uint64_t o = i % chunk16;
+  reinterpret_cast<uint4*>(dst.p[h])[o] = src[(uint64_t)h * chunk16 + o];
+}
+
 // out[j] = values[global(j)], 32-byte elements: the C query's witness values of a block-cyclic shard
 static __global__ __launch_bounds__(256) void gather_bc32_kernel(const uint4* __restrict__ values, uint64_t count,
                                                                  uint32_t bc_log, uint32_t bc_rank, uint32_t bc_world,

@@ -5,8 +5,9 @@
 // no process group: ONE process, one zkpoa_context per device each driven by its own host thread ("rank"), the key
 // sharded straight from the file's byte ranges (zkey_load_impl: block-cyclic sections 5-8, cyclic section 9, the
 // coefficient rows c = rank mod G), the H-scalar chain split as in zkpoa_split_stage1/2/3 with its two all-to-all
-// exchanges done as peer-to-peer copies over xGMI (hipMemcpyPeerAsync: every rank pushes chunk h of its buffer to rank
-// h in a single hop, all links busy at once, no ring), and the five 64/128-byte partial results summed on the host.
+// exchanges done as peer-to-peer writes over xGMI (one kernel per rank and exchange stores chunk h of its buffer straight
+// into rank h's receive buffer: a single hop, all links busy at once, no ring; hipMemcpyPeerAsync where a pair has no
+// direct path), and the five 64/128-byte partial results summed on the host.
 // Included by prover.hip inside its anonymous namespace.
 //
 // Which devices (env, read once per process):
@@ -54,6 +55,7 @@ struct DeviceSet {
   std::vector<zkpoa_context*> ctx;     // one context per rank (ranks that share a device have their own streams)
   std::vector<int> lock_fds;           // automatic selection: the GPUs' lock files, held until the process ends
   bool automatic = false;
+  bool peer_ok = true;                 // every rank can address every other rank's memory (peer access enabled)
 };
 
 std::mutex g_devset_mutex;
@@ -196,7 +198,10 @@ DeviceSet* process_devices(uint32_t power, std::string& err) {
         ZK_HIP(hipSetDevice(ds->ids[g]));
         if (hipDeviceCanAccessPeer(&can, ds->ids[g], ds->ids[h]) == hipSuccess && can) {
           hipError_t pe = hipDeviceEnablePeerAccess(ds->ids[h], 0);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) ds->peer_ok = false;
           if (pe != hipSuccess) (void)hipGetLastError();   // already enabled (devices listed twice), or not: copies still work
+        } else {
+          ds->peer_ok = false;   // no direct path between this pair: the exchanges go through hipMemcpyPeerAsync
         }
       }
     if (getenv("ZKPOA_VERBOSE")) {
@@ -313,12 +318,26 @@ void multi_push(DeviceSet* ds, MultiKey* mk, size_t g, const void* src, std::vec
   const size_t G = ds->ids.size();
   const uint64_t chunk = mk->xbytes / G;
   hipStream_t st = ds->ctx[g]->dev.lanes[0].stream;
-  for (size_t k = 0; k < G; k++) {
-    const size_t h = (g + k) % G;   // start with the own slot, then round the ring: no two ranks aim at one peer at once
-    const char* s = reinterpret_cast<const char*>(src) + h * chunk;
-    char* d = reinterpret_cast<char*>(dst[h]) + g * chunk;
-    if (ds->ids[g] == ds->ids[h]) ZK_HIP(hipMemcpyAsync(d, s, chunk, hipMemcpyDeviceToDevice, st));
-    else ZK_HIP(hipMemcpyPeerAsync(d, ds->ids[h], s, ds->ids[g], chunk, st));
+  static const bool force_copies = [] {
+    const char* e = getenv("ZKPOA_EXCHANGE");
+    return e && !strcmp(e, "copy");
+  }();
+  if (ds->peer_ok && !force_copies && chunk % 16 == 0) {
+    // one kernel writes all G chunks into the peers' receive buffers: all links busy at once (abc.hip.h)
+    XchgDst d;
+    for (size_t h = 0; h < 8; h++) d.p[h] = h < G ? reinterpret_cast<char*>(dst[h]) + g * chunk : nullptr;
+    const uint64_t chunk16 = chunk / 16, total = chunk16 * G;
+    hipLaunchKernelGGL(xchg_push_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const uint4*>(src), d, chunk16, (uint32_t)G, (uint32_t)g);
+    ZK_HIP(hipGetLastError());
+  } else {
+    for (size_t k = 0; k < G; k++) {
+      const size_t h = (g + k) % G;   // start with the own slot, then round the ring: no two ranks aim at one peer at once
+      const char* s = reinterpret_cast<const char*>(src) + h * chunk;
+      char* d = reinterpret_cast<char*>(dst[h]) + g * chunk;
+      if (ds->ids[g] == ds->ids[h]) ZK_HIP(hipMemcpyAsync(d, s, chunk, hipMemcpyDeviceToDevice, st));
+      else ZK_HIP(hipMemcpyPeerAsync(d, ds->ids[h], s, ds->ids[g], chunk, st));
+    }
   }
   ZK_HIP(hipEventRecord(done, st));
 }
