@@ -293,6 +293,17 @@ static __global__ __launch_bounds__(256) void xchg_push_kernel(const uint4* __re
   reinterpret_cast<uint4*>(dst.p[h])[o] = src[(uint64_t)h * chunk16 + o];
 }
 
+// The witness of a multi-GPU proof: every rank uploads 1 / G of it over its own PCIe link and this kernel stores that
+// slice into the G - 1 other ranks' witness buffers over xGMI (dst.p[h] = the slice's place in rank h's buffer).
+static __global__ __launch_bounds__(256) void xchg_bcast_kernel(const uint4* __restrict__ src, XchgDst dst, uint64_t n16,
+                                                                uint32_t G, uint32_t self) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n16 * (G - 1u)) return;
+  const uint32_t h = (self + 1u + (uint32_t)(i / n16)) % G;
+  const uint64_t o = i % n16;
+  reinterpret_cast<uint4*>(dst.p[h])[o] = src[o];
+}
+
 // out[j] = values[global(j)], 32-byte elements: the C query's witness values of a block-cyclic shard
 static __global__ __launch_bounds__(256) void gather_bc32_kernel(const uint4* __restrict__ values, uint64_t count,
                                                                  uint32_t bc_log, uint32_t bc_rank, uint32_t bc_world,

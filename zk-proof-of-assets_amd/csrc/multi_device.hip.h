@@ -226,6 +226,7 @@ struct MultiKey {
   bool split = false;                       // H-scalar chain split (G in {2, 4, 8}, G^2 <= domain) or replicated
   std::vector<void*> xa, xb1, xb2;          // per rank: send buffer, receive buffers of the two exchanges
   std::vector<hipEvent_t> ev1, ev2;         // per rank: "my pushes of exchange 1 / 2 are enqueued up to here"
+  std::vector<hipEvent_t> evw;              // per rank: "my slice of the witness is on its way to every peer"
   uint64_t xbytes = 0;                      // bytes of one exchange buffer: 3 * (domain / G) * 32
   uint64_t proofs_done = 0, table_bytes = 0;
   double load_ms = 0;
@@ -240,6 +241,7 @@ void multi_key_release(DeviceSet* ds, MultiKey* mk) {
       if (g < v->size() && (*v)[g]) (void)hipFree((*v)[g]);
     if (g < mk->ev1.size() && mk->ev1[g]) (void)hipEventDestroy(mk->ev1[g]);
     if (g < mk->ev2.size() && mk->ev2[g]) (void)hipEventDestroy(mk->ev2[g]);
+    if (g < mk->evw.size() && mk->evw[g]) (void)hipEventDestroy(mk->evw[g]);
     if (mk->shards[g]) {
       mk->shards[g]->release();
       delete mk->shards[g];
@@ -288,6 +290,11 @@ MultiKey* multi_key_load(DeviceSet* ds, const uint8_t* buf, uint64_t size) {
     mk->split = (G == 2 || G == 4 || G == 8) && (uint64_t)hdr->domain >= (uint64_t)G * G;
     const uint32_t bc = multi_block_log(hdr->nVars, G);
     for_each_rank(ds, [&](size_t g) { mk->shards[g] = zkey_load_impl(ds->ctx[g], buf, size, g, G, mk->split, bc); });
+    mk->evw.assign(G, nullptr);
+    for (size_t g = 0; g < G; g++) {
+      ZK_HIP(hipSetDevice(ds->ids[g]));
+      ZK_HIP(hipEventCreateWithFlags(&mk->evw[g], hipEventDisableTiming));
+    }
     if (mk->split) {
       mk->xbytes = (uint64_t)3 * (hdr->domain / G) * 32;
       mk->xa.assign(G, nullptr);
@@ -314,15 +321,19 @@ MultiKey* multi_key_load(DeviceSet* ds, const uint8_t* buf, uint64_t size) {
 
 // One exchange of the split chain, rank g's half: push chunk h of `src` (what rank h needs from g) into slot g of rank
 // h's receive buffer, all on g's lane-0 stream behind the stage that produced `src`; then mark the stream.
+inline bool multi_force_copies() {   // ZKPOA_EXCHANGE=copy: hipMemcpyPeerAsync exchanges, whole witness per rank
+  static const bool v = [] {
+    const char* e = getenv("ZKPOA_EXCHANGE");
+    return e && !strcmp(e, "copy");
+  }();
+  return v;
+}
+
 void multi_push(DeviceSet* ds, MultiKey* mk, size_t g, const void* src, std::vector<void*>& dst, hipEvent_t done) {
   const size_t G = ds->ids.size();
   const uint64_t chunk = mk->xbytes / G;
   hipStream_t st = ds->ctx[g]->dev.lanes[0].stream;
-  static const bool force_copies = [] {
-    const char* e = getenv("ZKPOA_EXCHANGE");
-    return e && !strcmp(e, "copy");
-  }();
-  if (ds->peer_ok && !force_copies && chunk % 16 == 0) {
+  if (ds->peer_ok && !multi_force_copies() && chunk % 16 == 0) {
     // one kernel writes all G chunks into the peers' receive buffers: all links busy at once (abc.hip.h)
     XchgDst d;
     for (size_t h = 0; h < 8; h++) d.p[h] = h < G ? reinterpret_cast<char*>(dst[h]) + g * chunk : nullptr;
@@ -365,10 +376,41 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       zkpoa_context* ctx = ds->ctx[g];
       zkpoa_zkey* zk = mk->shards[g];
       hipStream_t st = nullptr;
+      // The witness is needed whole on every rank. Each rank uploads 1 / G of it over its own PCIe link and stores that
+      // slice into the other ranks' buffers over xGMI (61 M wires = 2 GB: 8 x 2 GB through the host would cost twice
+      // the proof); ranks without a direct path to each other upload it whole.
+      const bool sliced = ds->peer_ok && G > 1 && !multi_force_copies();
       phase([&] {
         ZK_HIP(hipSetDevice(ds->ids[g]));
         st = ctx->dev.lanes[0].stream;
-        ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, st);   // replicated
+        if (sliced) {
+          const uint64_t lo = (uint64_t)w.n * g / G, hi = (uint64_t)w.n * (g + 1) / G;
+          char* mine = reinterpret_cast<char*>(zk->d_witness) + lo * 32;
+          if (hi > lo) {
+            ctx->uploader.upload(mine, w.values + lo * 32, (size_t)(hi - lo) * 32, ctx->dev.device, st);
+            XchgDst d;
+            for (size_t h = 0; h < 8; h++) d.p[h] = h < G ? reinterpret_cast<char*>(mk->shards[h]->d_witness) + lo * 32 : nullptr;
+            const uint64_t n16 = (hi - lo) * 2, total = n16 * (G - 1);
+            hipLaunchKernelGGL(xchg_bcast_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const uint4*>(mine), d, n16, (uint32_t)G, (uint32_t)g);
+            ZK_HIP(hipGetLastError());
+          }
+          ZK_HIP(hipEventRecord(mk->evw[g], st));
+        } else {
+          ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, st);   // replicated
+        }
+      });
+      if (sliced) {
+        bar.arrive_and_wait();   // every slice's event has been recorded
+        phase([&] {
+          for (size_t h = 0; h < G; h++) ZK_HIP(hipStreamWaitEvent(st, mk->evw[h], 0));
+          // the witness MSMs run on other lanes: they wait for this point of lane 0 (prove_partials, ev_witness)
+          if (!ctx->ev_witness) ZK_HIP(hipEventCreateWithFlags(&ctx->ev_witness, hipEventDisableTiming));
+          ZK_HIP(hipEventRecord(ctx->ev_witness, st));
+          ctx->ev_witness_set = true;
+        });
+      }
+      phase([&] {
         zk->h_ready = false;
         if (mk->split) {
           split_stage1(ctx, zk, mk->xa[g]);
