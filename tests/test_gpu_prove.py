@@ -397,6 +397,25 @@ def test_prover_cli_several_ranks_2p16_vs_c_oracle(ctx, zk, tmp_path, witness_li
     assert (tmp_path / "proof_copy.json").read_text() == want
 
 
+@pytest.mark.parametrize("fail", ["2:1", "0:2", "3:3"])
+def test_a_failing_rank_ends_the_multi_rank_proof_with_an_error_not_a_hang(zk, tmp_path, fail):
+    """One rank of a four-rank proof fails (test hook) before the first barrier, between the two exchanges or before its
+    MSMs: the other ranks keep arriving at the barriers, the process exits non-zero with that rank's message within
+    seconds, and no output file appears -- the same call without the hook then proves normally."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_DEVICES="0,0,0,0")
+    env.pop("ZKPOA_SERVER", None)
+    argv = [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"]
+    rc = subprocess.run(argv, env=dict(env, ZKPOA_TEST_FAIL_RANK=fail), capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert rc.returncode != 0 and ("rank %s failed in phase %s" % tuple(fail.split(":"))) in rc.stderr, rc.stderr
+    assert not (tmp_path / "proof.json").exists() and not (tmp_path / "public.json").exists()
+    rc = subprocess.run(argv, env=env, capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert rc.returncode == 0 and (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"]
+
+
 def test_prover_cli_server_mode(zk, tmp_path):
     """ZKPOA_SERVER: same argv, exit codes and output bytes, but the proofs come from a resident prover
     process that keeps the key in HBM between calls (second call = cache hit)."""

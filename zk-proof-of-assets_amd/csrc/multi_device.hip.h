@@ -376,6 +376,15 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       zkpoa_context* ctx = ds->ctx[g];
       zkpoa_zkey* zk = mk->shards[g];
       hipStream_t st = nullptr;
+      // tests: ZKPOA_TEST_FAIL_RANK=<g>[:<phase>] makes rank g fail at the start of that phase (1 = before the first
+      // barrier, 2 = between the exchanges, 3 = before its MSMs): the other ranks must come back, not wait for ever
+      auto test_fail = [&](int at) {
+        const char* e = getenv("ZKPOA_TEST_FAIL_RANK");
+        if (!e) return;
+        const char* colon = strchr(e, ':');
+        if ((size_t)atoi(e) == g && (colon ? atoi(colon + 1) : 1) == at)
+          throw ProverError(PROVER_ERROR, "test: rank " + std::to_string(g) + " failed in phase " + std::to_string(at));
+      };
       // The witness is needed whole on every rank. Each rank uploads 1 / G of it over its own PCIe link and stores that
       // slice into the other ranks' buffers over xGMI (61 M wires = 2 GB: 8 x 2 GB through the host would cost twice
       // the proof); ranks without a direct path to each other upload it whole.
@@ -383,6 +392,7 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       phase([&] {
         ZK_HIP(hipSetDevice(ds->ids[g]));
         st = ctx->dev.lanes[0].stream;
+        test_fail(1);
         if (sliced) {
           const uint64_t lo = (uint64_t)w.n * g / G, hi = (uint64_t)w.n * (g + 1) / G;
           char* mine = reinterpret_cast<char*>(zk->d_witness) + lo * 32;
@@ -420,6 +430,7 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       if (mk->split) {
         bar.arrive_and_wait();   // every rank's event has been recorded: waiting on an unrecorded event is a no-op
         phase([&] {
+          test_fail(2);
           for (size_t h = 0; h < G; h++) ZK_HIP(hipStreamWaitEvent(st, mk->ev1[h], 0));
           split_stage2(ctx, zk, mk->xb1[g], mk->xa[g]);   // xa[g] is free: this stream's own pushes precede this stage
           multi_push(ds, mk, g, mk->xa[g], mk->xb2, mk->ev2[g]);
@@ -431,7 +442,10 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
         });
       }
       // the witness MSMs start at once on their own lanes and overlap the chain still in flight on lane 0
-      phase([&] { prove_partials(ctx, zk, parts[g].data()); });
+      phase([&] {
+        test_fail(3);
+        prove_partials(ctx, zk, parts[g].data());
+      });
       // a rank must not start the next proof's pushes into a peer that still reads this proof's buffers
       phase([&] { ZK_HIP(hipStreamSynchronize(st)); });
   };
