@@ -776,6 +776,10 @@ def main():
                 entry["leg_seconds"] = time.perf_counter() - t0
                 line["also"] = [entry]
         if rank == 0:
+            if world > 1 and default_workload:
+                line["scaling_note"] = ("strong scaling of ONE synthetic layer_one 2^26 proof (BASELINE.json configs[4]); the N = 1 "
+                                        "point of this curve is the `prove_2p26` entry under `also` of the N = 1 line (whose "
+                                        "headline is configs[1], the 2^20 MSM); the weak-scaling MSM of every N is under `also` here")
             line["n_ranks_seen"] = dist.get_world_size() if dist.is_initialized() else 1
             if dist.is_initialized():
                 line["collectives"] = dist.get_backend()
