@@ -56,6 +56,20 @@ def test_reference_anonymity_set_root(ctx):
         tree.close()
 
 
+def test_reference_height12_paths_on_the_device(ctx):
+    """The four height-12 sibling paths of tests/4_sigs_2_batches_12_height (layer_two_batch_{0,1}_input.json) folded with
+    the DEVICE hash: every level's four hashes in one zkpoa_poseidon2 call, ending at the committed merkle_root."""
+    from test_poseidon_oracle import height12_paths
+    paths = height12_paths()
+    nodes = _ints(ctx.poseidon2(b"".join(le(a) for a, _, _, _, _ in paths), b"".join(le(b) for _, b, _, _, _ in paths)))
+    assert nodes == [P.poseidon([a, b]) for a, b, _, _, _ in paths]
+    for lvl in range(11):
+        left = [p[3][lvl] if p[4][lvl] else nd for p, nd in zip(paths, nodes)]
+        right = [nd if p[4][lvl] else p[3][lvl] for p, nd in zip(paths, nodes)]
+        nodes = _ints(ctx.poseidon2(b"".join(le(x) for x in left), b"".join(le(x) for x in right)))
+    assert nodes == [p[2] for p in paths]
+
+
 def test_reference_merkle_path_fixture(ctx):
     """The sibling path the reference's Rust binary produced for leaf 3 of that set and fed to its layer-two circuit
     (tests/1_sigs_1_batches_5_height/layer_two/batch_0/layer_two_batch_0_input.json path_elements / path_indices)."""

@@ -73,6 +73,39 @@ def test_reference_merkle_path_fixture_oracles():
     assert node == root
 
 
+def height12_paths():
+    """The four sibling paths of the reference's height-12 test (tests/4_sigs_2_batches_12_height/layer_two/batch_{0,1}/
+    layer_two_batch_*_input.json): (leaf address, leaf balance, root, path elements, path indices) per owned leaf."""
+    out = []
+    for b in (0, 1):
+        d = json.load(open(os.path.join(GOLDEN, "ref", "merkle", "height12_layer_two_batch_%d_merkle_inputs.json" % b)))
+        for i in range(len(d["leaf_addresses"])):
+            out.append((int(d["leaf_addresses"][i]), int(d["leaf_balances"][i]), int(d["merkle_root"]),
+                        [int(x) for x in d["path_elements"][i]], [int(x) for x in d["path_indices"][i]]))
+    return out
+
+
+def test_reference_height12_paths_fold_to_the_root_in_both_oracles():
+    """No anonymity set is committed for the height-12 test, but its four sibling paths are: every one must fold, leaf
+    hash upwards, to the committed merkle_root -- which is also public[1] of both layer-two proofs of that test -- under
+    the Python oracle's Poseidon and under the C oracle's."""
+    paths = height12_paths()
+    assert len(paths) == 4 and all(len(e) == 11 and len(b) == 11 for _, _, _, e, b in paths)
+    for b in (0, 1):
+        pub = json.load(open(os.path.join(GOLDEN, "ref", "4_sigs_2_batches_12_height__layer_two__batch_%d" % b, "public.json")))
+        assert int(pub[1]) == paths[2 * b][2] == paths[2 * b + 1][2]
+    for addr, bal, root, elems, bits in paths:
+        node = P.poseidon([addr, bal])
+        c_node = int.from_bytes(co.poseidon2(le(addr), le(bal), 1), "little")
+        assert c_node == node
+        for e, bit in zip(elems, bits):
+            left, right = (e, node) if bit else (node, e)
+            node = P.poseidon([left, right])
+            c_node = int.from_bytes(co.poseidon2(le(left), le(right), 1), "little")
+            assert c_node == node
+        assert node == root
+
+
 def test_c_oracle_equals_python_oracle():
     rng = random.Random(7)
     xs = [0, 1, P.R - 1, 2 ** 160 - 1] + [rng.randrange(P.R) for _ in range(12)]

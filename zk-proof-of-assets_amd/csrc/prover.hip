@@ -1084,7 +1084,12 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   if (public_cap < (uint64_t)zk->nPublic * 32) throw ProverError(PROVER_ERROR_SHORT_BUFFER, "public buffer too small");
   Lane& l0 = ctx->dev.lanes[0];
   (void)l0;
-  ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
+  {
+    const auto tu = std::chrono::steady_clock::now();
+    ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
+    ctx->io_ms[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tu).count();
+    ctx->io_ms[1] = (float)((double)w.n * 32 / 1e6);
+  }
   prove_core(ctx, zk, r_le, s_le, proof_points);
   memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
   selfcheck(ctx, zk, proof_points, w.values + 32);
@@ -1368,10 +1373,11 @@ int emit_outputs(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t pts[256
   }
   if (getenv("ZKPOA_VERBOSE")) {
     fprintf(stderr,
-            "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | h-chain %.2f ms, "
-            "msm phase %.2f ms, prove %.2f ms, self-check %.2f ms\n",
+            "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | witness -> HBM %.2f ms "
+            "(%.0f MB, %.1f GB/s) | h-chain %.2f ms, msm phase %.2f ms, prove %.2f ms, self-check %.2f ms\n",
             zk->nVars, zk->nPublic, zk->power, (unsigned long long)zk->nCoefs, how, load_ms,
-            load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5], ctx->ms[6]);
+            load_ms > 0 ? (double)zkey_size / load_ms / 1e6 : 0.0, ctx->io_ms[0], ctx->io_ms[1],
+            ctx->io_ms[0] > 0 ? ctx->io_ms[1] / ctx->io_ms[0] : 0.0, ctx->ms[3], ctx->ms[4], ctx->ms[5], ctx->ms[6]);
   }
   return rc;
 }

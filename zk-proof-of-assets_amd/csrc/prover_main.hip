@@ -86,10 +86,13 @@ static double now_ms() {
 static int prove_files(const char* zkey, const char* wtns_path, const char* proof_path, const char* public_path,
                        std::string& message, bool* runtime_failure = nullptr) {
   MappedFile wtns;
+  const double t_map = now_ms();
   if (!wtns.open_file(wtns_path)) {
     message = std::string("Error: cannot read witness file ") + wtns_path;
     return EXIT_FAILURE;
   }
+  if (getenv("ZKPOA_VERBOSE"))
+    fprintf(stderr, "zkpoa: witness file mapped (%.1f MB) in %.2f ms\n", wtns.size / 1e6, now_ms() - t_map);
   static const char kEmpty[1] = {0};
   const void* wtns_data = wtns.p ? wtns.p : kEmpty;
   unsigned long proof_size = 1 << 12, public_size = 1 << 16;

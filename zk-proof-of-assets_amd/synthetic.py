@@ -251,6 +251,42 @@ class SyntheticCircuit:
             (1, (32).to_bytes(4, "little") + R_MOD.to_bytes(32, "little") + self.m.to_bytes(4, "little")),
             (2, self.witness_bytes())])
 
+    def write_zkey(self, path, chunk_bytes=256 << 20):
+        """zkey_image() written straight to `path`, the point sections streamed out of HBM in chunks: the layer-two /
+        layer-three shapes are 13 / 30 GB files, which zkey_image() would hold three times over in host memory."""
+        if self.shard is not None:
+            raise RuntimeError("write_zkey needs the unsharded circuit")
+        m, npub, hp = self.m, self.n_public, self.header_points
+        sec2 = (b"".join([(32).to_bytes(4, "little"), Q_MOD.to_bytes(32, "little"), (32).to_bytes(4, "little"),
+                          R_MOD.to_bytes(32, "little"), m.to_bytes(4, "little"), npub.to_bytes(4, "little"),
+                          self.n.to_bytes(4, "little")]) + hp[0:64] + hp[64:128] + hp[128:256] + hp[128:256] +
+                hp[256:320] + hp[320:448])
+        small = [(1, (1).to_bytes(4, "little")), (2, sec2), (3, bytes(64 * (npub + 1)))]
+        tensors = [(5, self.d_A, m * 64), (6, self.d_B1, m * 64), (7, self.d_B2, m * 128),
+                   (8, self.d_C, (m - npub - 1) * 64), (9, self.d_H, self.n * 64)]
+        with open(path, "wb") as f:
+            f.write(b"zkey" + (1).to_bytes(4, "little") + (4 + len(tensors)).to_bytes(4, "little"))
+            for sid, payload in small:
+                f.write(int(sid).to_bytes(4, "little") + len(payload).to_bytes(8, "little") + payload)
+            sec4 = self.coeff_section()
+            f.write((4).to_bytes(4, "little") + int(sec4.nbytes).to_bytes(8, "little"))
+            f.write(memoryview(sec4))
+            for sid, t, nbytes in tensors:
+                f.write(int(sid).to_bytes(4, "little") + int(nbytes).to_bytes(8, "little"))
+                for off in range(0, nbytes, chunk_bytes):
+                    f.write(memoryview(t[off:min(off + chunk_bytes, nbytes)].cpu().numpy()))
+        return path
+
+    def write_wtns(self, path):
+        """wtns_image() written to `path` without an intermediate copy of the values."""
+        with open(path, "wb") as f:
+            hdr = (32).to_bytes(4, "little") + R_MOD.to_bytes(32, "little") + self.m.to_bytes(4, "little")
+            f.write(b"wtns" + (2).to_bytes(4, "little") + (2).to_bytes(4, "little"))
+            f.write((1).to_bytes(4, "little") + len(hdr).to_bytes(8, "little") + hdr)
+            f.write((2).to_bytes(4, "little") + int(self.w_limbs.nbytes).to_bytes(8, "little"))
+            f.write(memoryview(self.w_limbs).cast("B"))
+        return path
+
     def prove(self, r=0, s=0):
         return self.ctx.prove_device(self.key, self.d_witness.data_ptr(), r, s)
 
