@@ -61,6 +61,16 @@ int groth16_prover_zkey_file(const char* zkey_file_path,
                              char* public_buffer, unsigned long* public_size,
                              char* error_msg, unsigned long error_msg_maxsize);
 
+/* Same again with BOTH inputs as paths -- exactly the argv of the process exec'd at scripts/g16_prove.sh:248-252
+ * (`prover <zkey> <wtns> ...`), and what the `prover` executable calls. Extension (rapidsnark's prover.h has no such
+ * entry): the witness is never mapped or copied on the host -- its values go from the page cache straight into the
+ * pinned staging buffers of the upload (pread), which at the layer-three size (1.7 GB .wtns) saves the ~50 ms a mapping
+ * costs to populate and tear down. Same return codes, buffers and environment as groth16_prover_zkey_file. */
+int zkpoa_groth16_prover_files(const char* zkey_file_path, const char* wtns_file_path,
+                               char* proof_buffer, unsigned long* proof_size,
+                               char* public_buffer, unsigned long* public_size,
+                               char* error_msg, unsigned long error_msg_maxsize);
+
 /* ---- context ----------------------------------------------------------------------------- */
 typedef struct zkpoa_context zkpoa_context;
 typedef struct zkpoa_zkey zkpoa_zkey;

@@ -131,12 +131,15 @@ def test_prover_server_lifecycle_without_gpu(zk, tmp_path):
     try:
         rc = subprocess.run([zk.PROVER_BIN, "c.zkey", "w.wtns", "proof.json", "public.json"], env=env, cwd=tmp_path,
                             capture_output=True, text=True, timeout=120)
-        assert rc.returncode == 1 and "no HIP device" in rc.stderr
-        assert os.path.exists(sock)                                  # the server is up and answered
+        # a HIP runtime that cannot come up is a runtime failure (PROVER_ERROR_RUNTIME), not an input error: the server
+        # says so and leaves (the next call starts a fresh one), the client logs it, tries in its own process and
+        # fails as loudly
+        assert rc.returncode == 1 and "no HIP device" in rc.stderr and "reported a GPU runtime failure" in rc.stderr
         assert not (tmp_path / "proof.json").exists() and not (tmp_path / "public.json").exists()
         rc = subprocess.run([zk.PROVER_BIN, "c.zkey", "missing.wtns", "proof.json", "public.json"], env=env,
                             cwd=tmp_path, capture_output=True, text=True, timeout=120)
         assert rc.returncode == 1 and "cannot read witness file" in rc.stderr
+        assert os.path.exists(sock)                                  # an input error: the (new) server answered and stays
     finally:
         rc = subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
     assert rc.returncode == 0
@@ -170,14 +173,17 @@ def test_prover_server_failure_paths_without_gpu(zk, tmp_path):
     # (2) a silent connection is dropped after the receive timeout and the next request is served
     sock = str(tmp_path / "quiet.sock")
     env = dict(os.environ, ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="30", ZKPOA_SERVER_RCV_TIMEOUT_S="1")
+    # (requests that fail on their INPUT -- a missing witness -- so that the server stays up on this GPU-less box: a HIP
+    # runtime that cannot start makes it leave, see test_prover_server_lifecycle_without_gpu)
+    argv_bad = [zk.PROVER_BIN, "c.zkey", "missing.wtns", "proof.json", "public.json"]
     try:
-        rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        rc = subprocess.run(argv_bad, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=120)
         assert os.path.exists(sock)
         quiet = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         quiet.connect(sock)                                           # ... and never sends a byte
         t0 = time.time()
-        rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=60)
-        assert rc.returncode == 1 and "no HIP device" in rc.stderr and "in-process" not in rc.stderr
+        rc = subprocess.run(argv_bad, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert rc.returncode == 1 and "cannot read witness file" in rc.stderr and "in-process" not in rc.stderr
         assert time.time() - t0 < 20
         quiet.close()
     finally:
@@ -213,3 +219,43 @@ def test_automatic_gpu_choice_of_the_multi_gpu_drop_in(zk):
     assert pick(8, 26, pid=13, busy=0b11111111) == [5]                         # nothing free: queue behind pid mod 8
     assert pick(2, 25, pid=9) == [0, 1] and pick(3, 25, pid=9) == [0, 1] and pick(16, 26, pid=1) == list(range(8))
     assert pick(8, 23, pid=2, min_power=23) == list(range(8))                  # ZKPOA_MULTI_MIN_POWER
+
+
+def test_block_size_of_the_block_cyclic_shards(zk):
+    """csrc/multi_device.hip.h multi_block_log_default (test hook, no GPU): sections 5-8 are dealt out in blocks of 2^16
+    items, fewer for small keys so that every rank still holds at least eight blocks, never fewer than 2^4."""
+    import ctypes
+    f = zk.lib().zkpoa_test_multi_block_log
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint]
+    f.restype = ctypes.c_uint
+    # the reference's shapes: layer one (2.08 M wires: 31 blocks of 2^16), two (21.4 M), three (52.4 M)
+    assert [f(2083343, g) for g in (1, 2, 4, 8)] == [16, 16, 15, 14]
+    assert [f(21356921, g) for g in (1, 2, 4, 8)] == [16] * 4 and [f(52367163, g) for g in (2, 4, 8)] == [16] * 3
+    for n, g in [(0, 1), (1, 8), (15, 2), (16, 1), (127, 1), (128, 1), (60000, 2), (60000, 8), (7000, 4), (1 << 19, 1), ((1 << 19) - 1, 1),
+                 (1 << 32, 8)]:
+        L = f(n, g)
+        assert 4 <= L <= 16
+        assert L == 4 or (n >> L) >= 8 * g            # at least eight blocks per rank ...
+        assert L == 16 or (n >> (L + 1)) < 8 * g       # ... and the largest block size that still gives that many
+    assert f(0, 1) == 4 and f(128, 1) == 4 and f(1 << 19, 1) == 16 and f((1 << 19) - 1, 1) == 15
+
+
+def test_malformed_device_environment_is_an_input_error(zk, tmp_path):
+    """ZKPOA_DEVICE / ZKPOA_SHARD_BLOCK_LOG / ZKPOA_MULTI_MIN_POWER are parsed with range checks: a bad value
+    fails the call with a message naming the variable (no GPU needed: nothing is proved on this box anyway, but the
+    input error must come first wherever a device count is not needed to see it)."""
+    import subprocess
+    g = golden_case("n8")
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "w.wtns").write_bytes(g["witness.wtns"])
+    argv = [zk.PROVER_BIN, "c.zkey", "w.wtns", "proof.json", "public.json"]
+    import torch
+    for var, bad in (("ZKPOA_DEVICE", "7x"), ("ZKPOA_DEVICE", "-1"), ("ZKPOA_DEVICE", "99")):
+        env = dict(os.environ, **{var: bad})
+        env.pop("ZKPOA_SERVER", None)
+        rc = subprocess.run(argv, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert rc.returncode == 1 and not (tmp_path / "proof.json").exists()
+        if torch.cuda.is_available():
+            assert var in rc.stderr, rc.stderr
+        else:
+            assert "no HIP device" in rc.stderr or var in rc.stderr

@@ -127,6 +127,28 @@ def test_msm_forced_windows(ctx, c):
     assert got == co.msm_g1(bases, sc, n, 8)
 
 
+def test_scan_look_back_gives_up_with_an_error_not_a_hang(zk):
+    """A tile prefix that is never published (r03: a host-side ordering mistake wiped live status words and the look-back
+    span for ever) must come back as an error: with tile 0 withholding its prefix (test option) and the poll limit
+    lowered, the MSM fails with the scan's message within seconds, and the same context computes correctly afterwards."""
+    rng = random.Random(11)
+    n = 40000
+    bases = co.fixed_base_g1(b"".join(le(rng.randrange(R)) for _ in range(n)), 8)
+    sc = _rand_scalars(rng, n, "witness")
+    c = zk.Context(0)
+    try:
+        c.set_option("msm_c", 14)                  # 19 windows x 8192 buckets: 76 scan tiles
+        c.set_option("scan_poll_limit_log2", 12)
+        c.set_option("scan_test_withhold", 1)
+        with pytest.raises(zk.ZkpoaError, match="scan look-back gave up"):
+            c.msm_g1(bases, sc, n)
+        c.set_option("scan_test_withhold", 0)
+        c.set_option("scan_poll_limit_log2", 24)
+        assert c.msm_g1(bases, sc, n) == co.msm_g1(bases, sc, n, 8)
+    finally:
+        c.close()
+
+
 def test_msm_chunked(ctx):
     """An MSM over more points than one bucket sort may index (n x windows < 2^32: 2^27 points by default) runs
     in chunks added on the host; "msm_max_points" forces that path at a size the oracle can check."""

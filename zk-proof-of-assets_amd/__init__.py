@@ -31,7 +31,7 @@ EXPORTS = [
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
     "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute", "zkpoa_wtns_check",
-    "zkpoa_zkey_load_shard", "zkpoa_zkey_load_shard_ex", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
+    "zkpoa_groth16_prover_files", "zkpoa_zkey_load_shard", "zkpoa_zkey_load_shard_ex", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
     "zkpoa_split_stage1", "zkpoa_split_stage2", "zkpoa_split_stage3",
@@ -805,6 +805,29 @@ def groth16_prove(zkey_path, wtns_path, proof_path, public_path):
                                             ctypes.byref(usz), err, 1024)
     if rc != PROVER_OK:
         raise ZkpoaError("groth16_prover failed (%d): %s" % (rc, err.value.decode()))
+    for path, text in ((proof_path, proof.value), (public_path, public.value)):
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(text)
+        os.replace(tmp, path)
+
+
+def groth16_prove_files(zkey_path, wtns_path, proof_path, public_path):
+    """The same step with both inputs as paths (zkpoa_groth16_prover_files: what the `prover` executable calls; the
+    witness goes from the page cache straight into the upload's pinned buffers, never mapped or copied on the host)."""
+    psz = ctypes.c_ulong(1 << 12)
+    usz = ctypes.c_ulong(1 << 20)
+    proof = ctypes.create_string_buffer(psz.value)
+    public = ctypes.create_string_buffer(usz.value)
+    err = ctypes.create_string_buffer(1024)
+    fn = lib().zkpoa_groth16_prover_files
+    rc = fn(os.fsencode(zkey_path), os.fsencode(wtns_path), proof, ctypes.byref(psz), public, ctypes.byref(usz), err, 1024)
+    if rc == PROVER_ERROR_SHORT_BUFFER:
+        proof = ctypes.create_string_buffer(psz.value)
+        public = ctypes.create_string_buffer(usz.value)
+        rc = fn(os.fsencode(zkey_path), os.fsencode(wtns_path), proof, ctypes.byref(psz), public, ctypes.byref(usz), err, 1024)
+    if rc != PROVER_OK:
+        raise ZkpoaError("zkpoa_groth16_prover_files failed (%d): %s" % (rc, err.value.decode()))
     for path, text in ((proof_path, proof.value), (public_path, public.value)):
         tmp = "%s.tmp.%d" % (path, os.getpid())
         with open(tmp, "wb") as f:

@@ -75,6 +75,15 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
   // (re)allocated -- every call stamps its words with the next generation number
   void* scan_scratch = nullptr;
   uint32_t scan_tiles = 0, scan_gen = 0;
+  // The look-back of scan_pair waits for words other workgroups publish: a wait that can never end (an ordering mistake
+  // on the host side, a wiped scratch) must surface as an error, not as a hung GPU. After scan_poll_limit polls of one
+  // word a wavefront gives up, raises the lane's fault word -- the last 64 bytes of the pinned staging area, which the
+  // host looks at after every read-back -- and carries on with a zero prefix so that the grid still drains.
+  // scan_test_withhold (tests only, zkpoa_set_option): tile 0 never publishes its prefix.
+  uint32_t scan_poll_limit = 1u << 24, scan_test_withhold = 0;
+  static constexpr size_t kFaultBytes = 64;
+  volatile uint32_t* fault_word() const { return reinterpret_cast<volatile uint32_t*>(static_cast<char*>(pinned) + pinned_cap); }
+  uint32_t* fault_word_dev() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(pinned_dev) + pinned_cap); }
   // level 2 = highest, 1 = middle, 0 = lowest stream priority
   void init(int level = 0) {
     int lo = 0, hi = 0;  // numerically lower = higher priority
@@ -82,10 +91,11 @@ struct Lane {  // one stream + its workspace + a pinned host staging area for sm
     int prio = level >= 2 ? hi : (level == 1 ? (lo + hi) / 2 : lo);
     // creating the stream is the expensive part (10-50 ms: a hardware queue comes up with it)
     ZK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio));
-    pinned_cap = 1 << 20;
-    ZK_HIP(hipHostMalloc(&pinned, pinned_cap, hipHostMallocDefault));
+    pinned_cap = (1 << 20) - kFaultBytes;   // read-backs use [0, pinned_cap); the fault word sits behind them
+    ZK_HIP(hipHostMalloc(&pinned, pinned_cap + kFaultBytes, hipHostMallocDefault));
     ZK_HIP(hipHostGetDevicePointer(&pinned_dev, pinned, 0));
-    host_sums.assign(pinned_cap, 0);
+    memset(static_cast<char*>(pinned) + pinned_cap, 0, kFaultBytes);
+    host_sums.assign(pinned_cap + kFaultBytes, 0);
     ZK_HIP(hipEventCreate(&ev0));
     ZK_HIP(hipEventCreate(&ev1));
   }

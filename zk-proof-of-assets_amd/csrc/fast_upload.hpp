@@ -17,7 +17,7 @@ namespace zkpoa {
 
 class FastUploader {
  public:
-  static constexpr int kThreads = 6;
+  static constexpr int kMaxThreads = 16;
   // 2 MiB per buffer, two per thread: large enough for full-rate DMA, and pinning the staging memory is a
   // start-up cost that a one-shot prover pays every time (12 x 8 MiB cost ~60 ms, 12 x 2 MiB ~15 ms)
   static constexpr size_t kChunk = 2u << 20;
@@ -26,20 +26,27 @@ class FastUploader {
 
   // `stream`: an existing stream of the caller that is idle during the upload (the context's lane 0). Creating
   // a HIP stream costs 10-50 ms (it brings up a hardware queue), which a one-shot prover pays on every run, so
-  // the uploader owns none: the copies of all threads interleave on the one stream at full PCIe rate.
+  // the uploader owns none by default: the copies of all threads interleave on the one stream at full PCIe rate.
   // fd >= 0: the bytes are read with pread(fd, file_off + ...) straight into the pinned buffers instead of being
   // copied out of `src` (a fresh mmap of a page-cached 1 GB file costs a page fault per 64 KiB on top of the copy:
-  // ~10 GB/s; pread from the page cache runs at memcpy speed and skips the second copy).
+  // ~10 GB/s; pread from the page cache runs at memcpy speed and skips the second copy); `src` may then be null.
   void upload(void* dst, const void* src, size_t bytes, int device, hipStream_t stream, int fd = -1, uint64_t file_off = 0) {
     if (bytes < (4u << 20)) {  // small: not worth the threads
+      std::vector<char> tmp;
+      if (fd >= 0) {
+        tmp.resize(bytes);
+        read_all(fd, tmp.data(), bytes, file_off);
+        src = tmp.data();
+      }
       ZK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
       return;
     }
     ensure(device, stream);
+    const int T = threads_;
     std::vector<std::thread> th;
-    std::vector<std::exception_ptr> errs(kThreads);
-    size_t per = ((bytes / kThreads) + 4095) & ~size_t(4095);
-    for (int t = 0; t < kThreads; t++) {
+    std::vector<std::exception_ptr> errs(T);
+    size_t per = ((bytes / T) + 4095) & ~size_t(4095);
+    for (int t = 0; t < T; t++) {
       size_t lo = (size_t)t * per;
       if (lo >= bytes) break;
       size_t hi = lo + per < bytes ? lo + per : bytes;
@@ -47,22 +54,15 @@ class FastUploader {
         try {
           ZK_HIP(hipSetDevice(device));
           Slot& s = slots_[t];
+          hipStream_t st = own_streams_.empty() ? stream : own_streams_[t % own_streams_.size()];
           int b = 0;
           for (size_t off = lo; off < hi; off += kChunk, b ^= 1) {
             size_t len = hi - off < kChunk ? hi - off : kChunk;
             ZK_HIP(hipEventSynchronize(s.done[b]));  // the DMA that last used this buffer has finished
-            if (fd >= 0) {
-              size_t got = 0;
-              while (got < len) {
-                ssize_t r = pread(fd, static_cast<char*>(s.pinned[b]) + got, len - got, (off_t)(file_off + off + got));
-                if (r <= 0) throw HipError("zkey upload: short read from the key file");
-                got += (size_t)r;
-              }
-            } else {
-              memcpy(s.pinned[b], reinterpret_cast<const char*>(src) + off, len);
-            }
-            ZK_HIP(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, s.pinned[b], len, hipMemcpyHostToDevice, stream));
-            ZK_HIP(hipEventRecord(s.done[b], stream));
+            if (fd >= 0) read_all(fd, static_cast<char*>(s.pinned[b]), len, file_off + off);
+            else memcpy(s.pinned[b], reinterpret_cast<const char*>(src) + off, len);
+            ZK_HIP(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, s.pinned[b], len, hipMemcpyHostToDevice, st));
+            ZK_HIP(hipEventRecord(s.done[b], st));
           }
           for (int k = 0; k < 2; k++) ZK_HIP(hipEventSynchronize(s.done[k]));
         } catch (...) {
@@ -89,6 +89,8 @@ class FastUploader {
         s.done[b] = nullptr;
       }
     }
+    for (hipStream_t st : own_streams_) (void)hipStreamDestroy(st);
+    own_streams_.clear();
     if (block_) (void)hipHostFree(block_);
     block_ = nullptr;
     ready_ = false;
@@ -99,9 +101,20 @@ class FastUploader {
     void* pinned[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
   };
-  Slot slots_[kThreads];
+  Slot slots_[kMaxThreads];
   void* block_ = nullptr;
   bool ready_ = false;
+  int threads_ = 8;
+  std::vector<hipStream_t> own_streams_;   // ZKPOA_UPLOAD_STREAMS > 0 (experiments): copies spread over that many streams
+
+  static void read_all(int fd, char* out, size_t len, uint64_t pos) {
+    size_t got = 0;
+    while (got < len) {
+      ssize_t r = pread(fd, out + got, len - got, (off_t)(pos + got));
+      if (r <= 0) throw HipError("upload: short read from the file");
+      got += (size_t)r;
+    }
+  }
 
   std::mutex ensure_mutex_;
   void ensure(int device, hipStream_t stream) {
@@ -110,9 +123,25 @@ class FastUploader {
   }
   void ensure_locked(int device, hipStream_t stream) {
     if (ready_) return;
+    // Threads: each copies its slice through its own pair of pinned buffers. Measured on an MI355X box (r04,
+    // tools/file_inclusive.py): see DESIGN.md section 7 for the rates; ZKPOA_UPLOAD_THREADS overrides (1..16).
+    if (const char* e = getenv("ZKPOA_UPLOAD_THREADS")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= kMaxThreads) threads_ = v;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (int)hw < threads_) threads_ = (int)hw;
     ZK_HIP(hipSetDevice(device));
-    ZK_HIP(hipHostMalloc(&block_, (size_t)kThreads * 2 * kChunk, hipHostMallocDefault));   // one pinning call
-    for (int t = 0; t < kThreads; t++) {
+    if (const char* e = getenv("ZKPOA_UPLOAD_STREAMS")) {
+      const int v = atoi(e);
+      for (int i = 0; i < v && i < kMaxThreads; i++) {
+        hipStream_t st = nullptr;
+        ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        own_streams_.push_back(st);
+      }
+    }
+    ZK_HIP(hipHostMalloc(&block_, (size_t)threads_ * 2 * kChunk, hipHostMallocDefault));   // one pinning call
+    for (int t = 0; t < threads_; t++) {
       Slot& s = slots_[t];
       for (int b = 0; b < 2; b++) {
         s.pinned[b] = static_cast<char*>(block_) + ((size_t)t * 2 + b) * kChunk;

@@ -28,6 +28,7 @@
 #include "bn254_ec.hip.h"
 #include "device_ctx.hpp"
 #include <string.h>
+#include <chrono>
 #include <utility>
 
 namespace zkpoa {
@@ -338,11 +339,19 @@ ZK_DEV void scan_status_store(uint64_t* p, uint64_t v) {
 // tile's aggregate, walks back 64 predecessors at a time until one with an inclusive prefix is met, then publishes
 // its own inclusive prefix. status: [ntiles] words of (generation << 2 | state) << 32 | value; state 1 = aggregate,
 // 2 = inclusive prefix.
-ZK_DEV uint32_t scan_look_back(uint64_t* status, uint32_t tile, uint32_t aggregate, uint32_t gen) {
+// guard: a word that is never published (host-side ordering mistake, wiped scratch) ends the wait after poll_limit
+// polls: the lane raises the fault word in the lane's pinned host memory, takes the missing prefix as zero and goes on,
+// so every wavefront still reaches the end of the kernel; the host turns the fault word into an error (msm_read_back).
+struct ScanGuard {
+  uint32_t poll_limit;
+  uint32_t withhold;     // tests only: tile 0 does not publish
+  uint32_t* fault;       // host-pinned, device-addressable
+};
+ZK_DEV uint32_t scan_look_back(uint64_t* status, uint32_t tile, uint32_t aggregate, uint32_t gen, const ScanGuard& guard) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t tag1 = ((uint64_t)((gen << 2) | 1u)) << 32, tag2 = ((uint64_t)((gen << 2) | 2u)) << 32;
   if (tile == 0) {
-    if (lane == 0) scan_status_store(&status[0], tag2 | aggregate);
+    if (lane == 0 && !guard.withhold) scan_status_store(&status[0], tag2 | aggregate);
     return 0;
   }
   if (lane == 0) scan_status_store(&status[tile], tag1 | aggregate);
@@ -353,11 +362,22 @@ ZK_DEV uint32_t scan_look_back(uint64_t* status, uint32_t tile, uint32_t aggrega
     uint64_t w = 0;
     uint32_t state = 2, val = 0;     // lanes before tile 0: an inclusive prefix of nothing
     if (t >= 0) {
+      uint32_t polls = 0;
+      bool gave_up = false;
       do {
         w = scan_status_load(&status[t]);
+        if (++polls > guard.poll_limit) {
+          gave_up = true;
+          break;
+        }
       } while ((uint32_t)(w >> 34) != gen || (((uint32_t)(w >> 32)) & 3u) == 0);
       state = ((uint32_t)(w >> 32)) & 3u;
       val = (uint32_t)w;
+      if (gave_up) {   // counts as "prefix of nothing": the walk ends here, the result is wrong and flagged as such
+        __hip_atomic_store(guard.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        state = 2;
+        val = 0;
+      }
     }
     const uint64_t incl = __ballot(state == 2);          // non-zero: lanes below tile 0 count too
     const uint32_t stop = incl ? (uint32_t)__builtin_ctzll(incl) : 63u;   // nearest predecessor that knows its whole prefix
@@ -375,7 +395,7 @@ ZK_DEV uint32_t scan_look_back(uint64_t* status, uint32_t tile, uint32_t aggrega
 static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a, uint64_t* __restrict__ status_a,
                                                                       uint64_t* __restrict__ status_b,
                                                                       uint32_t* __restrict__ tickets, uint32_t gen,
-                                                                      uint32_t ntiles) {
+                                                                      uint32_t ntiles, ScanGuard guard) {
   __shared__ uint32_t lds[8];
   __shared__ uint32_t s_tile, s_pre_a, s_pre_b;
   if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[0], 1u);
@@ -403,8 +423,8 @@ static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a
   uint32_t ex_a = block_exclusive_scan(sum_a, lds, tot_a);
   uint32_t ex_b = two ? block_exclusive_scan(sum_b, lds, tot_b) : 0;
   if (threadIdx.x < 64) {
-    uint32_t pa = scan_look_back(status_a, tile, tot_a, gen);
-    uint32_t pb = two ? scan_look_back(status_b, tile, tot_b, gen) : 0;
+    uint32_t pa = scan_look_back(status_a, tile, tot_a, gen, guard);
+    uint32_t pb = two ? scan_look_back(status_b, tile, tot_b, gen, guard) : 0;
     if (threadIdx.x == 0) {
       s_pre_a = pa;
       s_pre_b = pb;
@@ -484,7 +504,19 @@ inline void scan_pair(Lane& lane, const ScanPair& a) {
   uint32_t* tickets = reinterpret_cast<uint32_t*>(lane.scan_scratch);
   uint64_t* st_a = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(lane.scan_scratch) + 256);
   uint64_t* st_b = st_a + lane.scan_tiles;
-  hipLaunchKernelGGL(scan_pair_kernel, dim3(ntiles), dim3(kScanBlock), 0, lane.stream, a, st_a, st_b, tickets, gen, ntiles);
+  const ScanGuard guard{lane.scan_poll_limit, lane.scan_test_withhold, lane.fault_word_dev()};
+  hipLaunchKernelGGL(scan_pair_kernel, dim3(ntiles), dim3(kScanBlock), 0, lane.stream, a, st_a, st_b, tickets, gen, ntiles,
+                     guard);
+}
+
+// After a synchronisation of the lane's stream: did a scan of this lane give up waiting? (The word is cleared, so the
+// lane is usable again -- the caller decides what the failure means for the context.)
+inline void lane_check_fault(Lane& lane) {
+  volatile uint32_t* f = lane.fault_word();
+  if (*f) {
+    *f = 0;
+    throw HipError("msm: a scan look-back gave up waiting for a tile prefix that was never published (result discarded)");
+  }
 }
 
 // ---- 4: accumulate --------------------------------------------------------------------------
@@ -818,6 +850,7 @@ inline void msm_read_back(Lane& lane, const void* d_src, size_t bytes) {
   hipLaunchKernelGGL(msm_to_host_kernel, dim3(grid ? grid : 1), dim3(256), 0, lane.stream, (const uint4*)d_src,
                      (uint4*)lane.pinned_dev, n16);
   ZK_HIP(hipStreamSynchronize(lane.stream));
+  lane_check_fault(lane);
 }
 
 // ---- host driver: two phases ---------------------------------------------------------------------
@@ -881,7 +914,11 @@ inline size_t msm_accum_workspace_bytes(const MsmPlan& p) {
 inline void lane_reserve(Lane& lane, size_t need) {
   if (lane.ws.cap < need) {
     ZK_HIP(hipStreamSynchronize(lane.stream));
+    const auto t0 = std::chrono::steady_clock::now();
     lane.ws.reserve(need);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 20.0 && getenv("ZKPOA_VERBOSE"))   // (only when a workspace grows: first proof on a key, or after precompute)
+      fprintf(stderr, "zkpoa:   lane workspace grows to %.2f GB: hipFree + hipMalloc %.1f ms\n", need / 1e9, ms);
   }
 }
 

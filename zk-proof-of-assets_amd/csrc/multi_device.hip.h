@@ -56,7 +56,32 @@ struct DeviceSet {
   std::vector<int> lock_fds;           // automatic selection: the GPUs' lock files, held until the process ends
   bool automatic = false;
   bool peer_ok = true;                 // every rank can address every other rank's memory (peer access enabled)
+  DeviceSet() = default;
+  DeviceSet(const DeviceSet&) = delete;
+  DeviceSet& operator=(const DeviceSet&) = delete;
+  // A set that never became the process's set (context creation or the peer-access loop failed) gives everything
+  // back: a retry in the same process (the resident server's next request) opens the lock files anew, and a lock this
+  // process still held through a leaked descriptor would make its own blocking flock wait for ever.
+  ~DeviceSet() {
+    for (auto* c : ctx)
+      if (c) zkpoa_context_destroy(c);
+    for (int fd : lock_fds)
+      if (fd >= 0) close(fd);
+  }
 };
+
+// env integer with a range, or `dflt` when unset / empty; a malformed or out-of-range value is an input error
+long env_long(const char* name, long lo, long hi, long dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = nullptr;
+  errno = 0;
+  const long v = strtol(e, &end, 10);
+  if (errno || end == e || *end || v < lo || v > hi)
+    throw ProverError(PROVER_ERROR, std::string(name) + "='" + e + "' is not an integer in [" + std::to_string(lo) + ", " +
+                                    std::to_string(hi) + "]");
+  return v;
+}
 
 std::mutex g_devset_mutex;
 DeviceSet* g_devset = nullptr;
@@ -83,11 +108,23 @@ int try_lock_gpu(int dev, bool block) {
   const std::string path = dir + "/gpu" + std::to_string(dev) + ".lock";
   int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
   if (fd < 0) return -1;
-  if (flock(fd, LOCK_EX | (block ? 0 : LOCK_NB)) != 0) {
-    close(fd);
-    return -1;
+  if (flock(fd, LOCK_EX | LOCK_NB) == 0) return fd;
+  if (block) {
+    // Wait for the holder, but not for ever: a wedged holder must not hang every later prover. After
+    // ZKPOA_GPU_LOCK_WAIT_S seconds (default 1800: a queue of layer-three proofs is minutes, not hours) the wait is
+    // reported and this process shares the GPU without the lock.
+    const long wait_s = env_long("ZKPOA_GPU_LOCK_WAIT_S", 0, 86400, 1800);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      if (flock(fd, LOCK_EX | LOCK_NB) == 0) return fd;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= (double)wait_s) break;
+      usleep(20000);
+    }
+    fprintf(stderr, "zkpoa: GPU %d: %s is still held after %ld s (another prover of this user; `fuser %s` names it); "
+                    "proceeding without the lock\n", dev, path.c_str(), wait_s, path.c_str());
   }
-  return fd;
+  close(fd);
+  return -1;
 }
 
 // The automatic choice, free of HIP and of the file system so that it can be tested without GPUs
@@ -140,7 +177,7 @@ void select_devices(DeviceSet& ds, uint32_t power) {
   }
   if (const char* e = getenv("ZKPOA_DEVICE")) {
     if (*e) {
-      ds.ids.push_back(atoi(e));
+      ds.ids.push_back((int)env_long("ZKPOA_DEVICE", 0, count - 1, 0));
       return;
     }
   }
@@ -149,8 +186,7 @@ void select_devices(DeviceSet& ds, uint32_t power) {
     return;
   }
   ds.automatic = true;
-  uint32_t min_power = 24;
-  if (const char* e = getenv("ZKPOA_MULTI_MIN_POWER")) min_power = (uint32_t)atoi(e);
+  const uint32_t min_power = (uint32_t)env_long("ZKPOA_MULTI_MIN_POWER", 0, 64, 24);
   std::vector<int> fds;
   ds.ids = auto_pick_devices(count, power, min_power, (unsigned long)getpid(), [&](int d, bool block) {
     int fd = try_lock_gpu(d, block);
@@ -167,10 +203,14 @@ void select_devices(DeviceSet& ds, uint32_t power) {
 
 // Contexts of the process, created once (first prove decides the device list). Ranks come up in parallel: a context
 // costs 60-200 ms (HIP runtime, first stream).
-DeviceSet* process_devices(uint32_t power, std::string& err) {
+// On failure nullptr with err / *code set: PROVER_ERROR for an input error (a malformed ZKPOA_* variable),
+// PROVER_ERROR_RUNTIME when the HIP runtime failed (no device, context creation, peer access) -- the caller reports it
+// as such, so a resident server goes away and the fault is logged instead of being retried on every request.
+DeviceSet* process_devices(uint32_t power, std::string& err, int* code) {
   std::lock_guard<std::mutex> lk(g_devset_mutex);
   if (g_devset) return g_devset;
-  std::unique_ptr<DeviceSet> ds(new DeviceSet());
+  if (code) *code = PROVER_ERROR;
+  std::unique_ptr<DeviceSet> ds(new DeviceSet());   // ~DeviceSet releases locks and contexts on every failure path
   try {
     auto t0 = std::chrono::steady_clock::now();
     select_devices(*ds, power);
@@ -185,11 +225,7 @@ DeviceSet* process_devices(uint32_t power, std::string& err) {
       });
     for (auto& t : th) t.join();
     for (size_t g = 0; g < G; g++)
-      if (!errs[g].empty()) {
-        for (auto* c : ds->ctx)
-          if (c) zkpoa_context_destroy(c);
-        throw HipError(errs[g]);
-      }
+      if (!errs[g].empty()) throw HipError(errs[g]);
     // peer access between distinct devices: the exchanges then go GPU to GPU over xGMI instead of through the host
     for (size_t g = 0; g < G; g++)
       for (size_t h = 0; h < G; h++) {
@@ -211,8 +247,13 @@ DeviceSet* process_devices(uint32_t power, std::string& err) {
               ds->automatic ? " (picked by lock file)" : "",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
-  } catch (const std::exception& e) {
+  } catch (const ProverError& e) {
     err = e.what();
+    if (code) *code = e.code;
+    return nullptr;
+  } catch (const std::exception& e) {   // HipError, bad_alloc, a thread that could not be started
+    err = e.what();
+    if (code) *code = PROVER_ERROR_RUNTIME;
     return nullptr;
   }
   g_devset = ds.release();
@@ -272,11 +313,19 @@ void for_each_rank(DeviceSet* ds, Fn fn) {
 
 // Block size of the block-cyclic sections: 2^16 items, less for small keys so that every rank still gets at least
 // eight blocks (and the test-size keys exercise the same path). ZKPOA_SHARD_BLOCK_LOG overrides; 0 = contiguous ranges.
-uint32_t multi_block_log(uint64_t n_vars, size_t G) {
-  if (const char* e = getenv("ZKPOA_SHARD_BLOCK_LOG")) return (uint32_t)atoi(e);
+uint32_t multi_block_log_default(uint64_t n_vars, size_t G) {
   uint32_t L = 16;
   while (L > 4 && (n_vars >> L) < 8 * (uint64_t)G) L--;
   return L;
+}
+uint32_t multi_block_log(uint64_t n_vars, size_t G) {
+  if (const char* e = getenv("ZKPOA_SHARD_BLOCK_LOG"))
+    if (*e) {
+      const long v = env_long("ZKPOA_SHARD_BLOCK_LOG", 0, 24, 0);
+      if (v != 0 && v < 4) throw ProverError(PROVER_ERROR, "ZKPOA_SHARD_BLOCK_LOG: 0 (contiguous ranges) or 4 .. 24");
+      return (uint32_t)v;
+    }
+  return multi_block_log_default(n_vars, G);
 }
 
 MultiKey* multi_key_load(DeviceSet* ds, const uint8_t* buf, uint64_t size) {
@@ -378,11 +427,15 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
       hipStream_t st = nullptr;
       // tests: ZKPOA_TEST_FAIL_RANK=<g>[:<phase>] makes rank g fail at the start of that phase (1 = before the first
       // barrier, 2 = between the exchanges, 3 = before its MSMs): the other ranks must come back, not wait for ever
+      // (read once per process: no getenv on the proving path)
       auto test_fail = [&](int at) {
-        const char* e = getenv("ZKPOA_TEST_FAIL_RANK");
-        if (!e) return;
-        const char* colon = strchr(e, ':');
-        if ((size_t)atoi(e) == g && (colon ? atoi(colon + 1) : 1) == at)
+        static const std::pair<long, long> hook = [] {
+          const char* e = getenv("ZKPOA_TEST_FAIL_RANK");
+          if (!e || !*e) return std::pair<long, long>(-1, 0);
+          const char* colon = strchr(e, ':');
+          return std::pair<long, long>(strtol(e, nullptr, 10), colon ? strtol(colon + 1, nullptr, 10) : 1);
+        }();
+        if (hook.first == (long)g && hook.second == at)
           throw ProverError(PROVER_ERROR, "test: rank " + std::to_string(g) + " failed in phase " + std::to_string(at));
       };
       // The witness is needed whole on every rank. Each rank uploads 1 / G of it over its own PCIe link and stores that
@@ -397,7 +450,7 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
           const uint64_t lo = (uint64_t)w.n * g / G, hi = (uint64_t)w.n * (g + 1) / G;
           char* mine = reinterpret_cast<char*>(zk->d_witness) + lo * 32;
           if (hi > lo) {
-            ctx->uploader.upload(mine, w.values + lo * 32, (size_t)(hi - lo) * 32, ctx->dev.device, st);
+            w.upload(ctx, mine, lo, hi - lo, st);
             XchgDst d;
             for (size_t h = 0; h < 8; h++) d.p[h] = h < G ? reinterpret_cast<char*>(mk->shards[h]->d_witness) + lo * 32 : nullptr;
             const uint64_t n16 = (hi - lo) * 2, total = n16 * (G - 1);
@@ -407,7 +460,7 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
           }
           ZK_HIP(hipEventRecord(mk->evw[g], st));
         } else {
-          ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, st);   // replicated
+          w.upload(ctx, zk->d_witness, 0, w.n, st);   // replicated
         }
       });
       if (sliced) {
@@ -461,6 +514,18 @@ void multi_prove_partials(DeviceSet* ds, MultiKey* mk, const WtnsView& w, uint8_
     }
   }
   for (auto& t : th) t.join();
+  if (failed.load()) {
+    // A failed proof skipped its last phase: peers' pushes and this proof's lane work may still be in flight, and a
+    // rank may have announced a witness event nobody consumed. Drain every rank (best effort) and reset that state
+    // before the error leaves, so that the next proof on this key does not depend on what this one left behind.
+    for (size_t g = 0; g < G; g++) {
+      (void)hipSetDevice(ds->ids[g]);
+      (void)hipDeviceSynchronize();
+      ds->ctx[g]->ev_witness_set = false;
+      mk->shards[g]->h_ready = false;
+    }
+    (void)hipSetDevice(ds->ids[0]);
+  }
   if (spawn_err) std::rethrow_exception(spawn_err);
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);
@@ -490,12 +555,12 @@ void multi_precompute(DeviceSet* ds, MultiKey* mk) {
 }
 
 // witness -> proof JSON on a loaded MultiKey (the multi-GPU twin of prove_to_json)
-int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const WtnsSrc& wsrc, char* proof_buffer,
                         unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
                         unsigned long error_msg_maxsize, uint64_t zkey_size, bool cache_hit) {
   zkpoa_zkey* z0 = mk->shards[0];
   zkpoa_context* c0 = ds->ctx[0];
-  WtnsView w = parse_wtns(wtns, wtns_size);
+  WtnsView w = parse_wtns(wsrc);
   if (w.n != z0->nVars)
     throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(z0->nVars) +
                                                          ", witness: " + std::to_string(w.n));
@@ -507,11 +572,13 @@ int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const uint8_t* wtns, uint64
   zkey_header_bytes(z0, header);
   prove_assemble(header, parts, rp, sp, pts);
   c0->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  selfcheck(c0, z0, pts, w.values + 32);
+  std::vector<uint8_t> pub_store;
+  const uint8_t* pubs = w.publics(z0->nPublic, pub_store);
+  selfcheck(c0, z0, pts, pubs);
   if (getenv("ZKPOA_VERBOSE"))
     fprintf(stderr, "zkpoa: one proof over %zu ranks: H-scalar chain %s, sections 5-8 %s, %.2f GB of fixed-base tables; "
                     "prove %.2f ms\n", ds->ids.size(), mk->split ? "split (2 peer-to-peer exchanges)" : "replicated",
             z0->bc_log ? "block-cyclic" : "contiguous ranges", mk->table_bytes / 1e9, c0->ms[5]);
-  return emit_outputs(c0, z0, pts, w.values + 32, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+  return emit_outputs(c0, z0, pts, pubs, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                       error_msg_maxsize, mk->load_ms, zkey_size, cache_hit ? "cached," : "sharded load");
 }

@@ -676,9 +676,46 @@ bool parse_decimal_mod_r(const char* s, uint8_t out[32]) {
   return true;
 }
 
+// Where a witness comes from: a complete .wtns image in memory (the rapidsnark-shaped entry points), or an open file
+// (the `prover` executable, zkpoa_groth16_prover_files): then only the few header bytes are ever read through the CPU
+// and the values go from the page cache straight into the uploader's pinned staging buffers (pread) -- mapping a 1.7 GB
+// layer-three witness first costs ~25 ms of page-table work before the first byte moves, and as much again to unmap.
+struct WtnsSrc {
+  const uint8_t* buf = nullptr;
+  uint64_t size = 0;
+  int fd = -1;
+};
+
 struct WtnsView {
-  const uint8_t* values = nullptr;
+  const uint8_t* values = nullptr;   // memory form; null in file form
   uint32_t n = 0;
+  int fd = -1;                       // file form: the values start at byte `off` of fd
+  uint64_t off = 0;
+  // values [first, first + count) -> out
+  void read(uint64_t first, uint64_t count, uint8_t* out) const {
+    if (fd < 0) {
+      memcpy(out, values + first * 32, (size_t)count * 32);
+      return;
+    }
+    size_t got = 0, want = (size_t)count * 32;
+    while (got < want) {
+      ssize_t r = pread(fd, out + got, want - got, (off_t)(off + first * 32 + got));
+      if (r <= 0) throw ProverError(PROVER_ERROR, "wtns file: short read");
+      got += (size_t)r;
+    }
+  }
+  // the public signals w[1 .. n_public] (standard form), valid while `store` lives
+  const uint8_t* publics(uint32_t n_public, std::vector<uint8_t>& store) const {
+    if (fd < 0) return values + 32;
+    store.resize((size_t)n_public * 32 + 1);
+    if (n_public) read(1, n_public, store.data());
+    return store.data();
+  }
+  // values [first, first + count) -> device memory at dst, on `st` (synchronised on return)
+  void upload(zkpoa_context* ctx, void* dst, uint64_t first, uint64_t count, hipStream_t st) const {
+    ctx->uploader.upload(dst, fd < 0 ? values + first * 32 : nullptr, (size_t)count * 32, ctx->dev.device, st, fd,
+                         off + first * 32);
+  }
 };
 
 WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
@@ -693,6 +730,56 @@ WtnsView parse_wtns(const uint8_t* buf, uint64_t size) {
   if (s2.len != (uint64_t)w.n * 32) throw ProverError(PROVER_ERROR, "wtns value section has the wrong size");
   w.values = s2.p;
   return w;
+}
+
+// the same container walk on an open file: 12 bytes per section header are read, payloads are skipped
+WtnsView parse_wtns_fd(int fd, uint64_t size) {
+  auto rd = [&](uint64_t pos, void* out, size_t len) {
+    size_t got = 0;
+    while (got < len) {
+      ssize_t r = pread(fd, static_cast<char*>(out) + got, len - got, (off_t)(pos + got));
+      if (r <= 0) throw ProverError(PROVER_ERROR, "wtns file: short read");
+      got += (size_t)r;
+    }
+  };
+  uint8_t head[12];
+  if (size < 12) throw ProverError(PROVER_ERROR, "wtns file: invalid file format (bad magic)");
+  rd(0, head, 12);
+  if (memcmp(head, "wtns", 4) != 0) throw ProverError(PROVER_ERROR, "wtns file: invalid file format (bad magic)");
+  if (rd_u32(head + 4) > 2) throw ProverError(PROVER_ERROR, "wtns file: version not supported");
+  const uint32_t nsec = rd_u32(head + 8);
+  uint64_t pos = 12, off1 = 0, len1 = 0, off2 = 0, len2 = 0;
+  bool have1 = false, have2 = false;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > size) throw ProverError(PROVER_ERROR, "wtns file: truncated section table");
+    uint8_t sh[12];
+    rd(pos, sh, 12);
+    const uint32_t id = rd_u32(sh);
+    const uint64_t len = rd_u64(sh + 4);
+    pos += 12;
+    if (len > size - pos) throw ProverError(PROVER_ERROR, "wtns file: truncated section");
+    if (id == 1 && !have1) { have1 = true; off1 = pos; len1 = len; }
+    if (id == 2 && !have2) { have2 = true; off2 = pos; len2 = len; }
+    pos += len;
+  }
+  if (!have1) throw ProverError(PROVER_ERROR, "missing section 1 (wtns header)");
+  uint8_t h1[40];
+  if (len1 < 40) throw ProverError(PROVER_ERROR, "wtns header: unsupported field size");
+  rd(off1, h1, 40);
+  if (rd_u32(h1) != 32) throw ProverError(PROVER_ERROR, "wtns header: unsupported field size");
+  if (memcmp(h1 + 4, kR, 32) != 0)
+    throw ProverError(PROVER_ERROR, "Curve of the witness does not match the curve of the proving key");
+  WtnsView w;
+  w.n = rd_u32(h1 + 36);
+  if (!have2) throw ProverError(PROVER_ERROR, "missing section 2 (wtns values)");
+  if (len2 != (uint64_t)w.n * 32) throw ProverError(PROVER_ERROR, "wtns value section has the wrong size");
+  w.fd = fd;
+  w.off = off2;
+  return w;
+}
+
+WtnsView parse_wtns(const WtnsSrc& src) {
+  return src.fd >= 0 ? parse_wtns_fd(src.fd, src.size) : parse_wtns(src.buf, src.size);
 }
 
 // a table covers the whole resident array: the handle's current range must be that array
@@ -1074,10 +1161,10 @@ void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_poi
   throw ProverError(PROVER_ERROR, std::string("self-check could not run: ") + msg);
 }
 
-void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size,
+void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const WtnsSrc& wsrc,
                 const uint8_t* r_le, const uint8_t* s_le, uint8_t proof_points[256], uint8_t* public_le,
                 uint64_t public_cap) {
-  WtnsView w = parse_wtns(wtns, wtns_size);
+  WtnsView w = parse_wtns(wsrc);
   if (w.n != zk->nVars)
     throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
                                                          ", witness: " + std::to_string(w.n));
@@ -1086,13 +1173,15 @@ void prove_impl(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, u
   (void)l0;
   {
     const auto tu = std::chrono::steady_clock::now();
-    ctx->uploader.upload(zk->d_witness, w.values, (size_t)w.n * 32, ctx->dev.device, ctx->dev.lanes[0].stream);
+    w.upload(ctx, zk->d_witness, 0, w.n, ctx->dev.lanes[0].stream);
     ctx->io_ms[0] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tu).count();
     ctx->io_ms[1] = (float)((double)w.n * 32 / 1e6);
   }
   prove_core(ctx, zk, r_le, s_le, proof_points);
-  memcpy(public_le, w.values + 32, (size_t)zk->nPublic * 32);
-  selfcheck(ctx, zk, proof_points, w.values + 32);
+  std::vector<uint8_t> pub_store;
+  const uint8_t* pubs = w.publics(zk->nPublic, pub_store);
+  memcpy(public_le, pubs, (size_t)zk->nPublic * 32);
+  selfcheck(ctx, zk, proof_points, pubs);
 }
 
 // ---- one-shot prove with the key upload overlapped ------------------------------------------
@@ -1155,7 +1244,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
     // each buffer is allocated by the uploader right before its section moves (hipMalloc of GBs is milliseconds each)
     struct Item { int id; void** dst; const uint8_t* src; uint64_t bytes; };
     const Item items[S_COUNT] = {
-        {S_WIT, &k->d_witness, w.values, m * 32}, {S_COEF, &d_recs, zs.s4.p + 4, zk->nCoefs * 44},
+        {S_WIT, &k->d_witness, w.values /* null: from w.fd */, m * 32}, {S_COEF, &d_recs, zs.s4.p + 4, zk->nCoefs * 44},
         {S_H, &k->dH, zs.s9.p, n * 64},           {S_B1, &k->dB1, zs.s6.p, m * 64},
         {S_B2, &k->dB2, zs.s7.p, m * 128},        {S_A, &k->dA, zs.s5.p, m * 64},
         {S_C, &k->dC, zs.s8.p, nC * 64}};
@@ -1167,7 +1256,17 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
           if (cancel.load()) throw ProverError(PROVER_ERROR, "upload cancelled");
           if (!*items[i].dst) ZK_HIP(hipMalloc(items[i].dst, items[i].bytes ? items[i].bytes : 1));
           if (items[i].bytes) {
-            if (items[i].bytes < (4u << 20)) {   // small: one asynchronous copy on the copy stream (no null-stream copy here)
+            if (items[i].id == S_WIT && w.fd >= 0) {   // file-backed witness: pread into the pinned staging buffers
+              std::vector<uint8_t> small;
+              if (items[i].bytes < (4u << 20)) {
+                small.resize(items[i].bytes);
+                w.read(0, w.n, small.data());
+                ZK_HIP(hipMemcpyAsync(*items[i].dst, small.data(), items[i].bytes, hipMemcpyHostToDevice, cs));
+                ZK_HIP(hipStreamSynchronize(cs));
+              } else {
+                ctx->uploader.upload(*items[i].dst, nullptr, items[i].bytes, ctx->dev.device, cs, w.fd, w.off);
+              }
+            } else if (items[i].bytes < (4u << 20)) {   // small: one asynchronous copy on the copy stream (no null-stream copy here)
               ZK_HIP(hipMemcpyAsync(*items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, cs));
               ZK_HIP(hipStreamSynchronize(cs));
             } else {
@@ -1334,7 +1433,7 @@ zkpoa_context* g_ctx = nullptr;
 std::mutex g_prove_mutex;   // one-shot entry points share the process-wide context: one proof at a time
 
 struct DeviceSet;
-DeviceSet* process_devices(uint32_t power, std::string& err);   // multi_device.hip.h: the device list of this process
+DeviceSet* process_devices(uint32_t power, std::string& err, int* code);   // multi_device.hip.h: the device list of this process
 
 // r, s from the environment (ZKPOA_R / ZKPOA_S, decimal; test use) -> pointers, or null for /dev/urandom
 void env_blinding(uint8_t rb[32], uint8_t sb[32], const uint8_t*& rp, const uint8_t*& sp) {
@@ -1383,7 +1482,7 @@ int emit_outputs(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t pts[256
 }
 
 // prove with a resident key, JSON out; options from the environment (ZKPOA_R / ZKPOA_S / ZKPOA_JSON / ZKPOA_VERBOSE)
-int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const WtnsSrc& wsrc, char* proof_buffer,
                   unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
                   unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, bool cache_hit) {
   uint8_t rb[32], sb[32];
@@ -1391,22 +1490,22 @@ int prove_to_json(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t* wtns,
   env_blinding(rb, sb, rp, sp);
   uint8_t pts[256];
   std::vector<uint8_t> pub((size_t)zk->nPublic * 32 + 1);
-  prove_impl(ctx, zk, wtns, wtns_size, rp, sp, pts, pub.data(), pub.size());
+  prove_impl(ctx, zk, wsrc, rp, sp, pts, pub.data(), pub.size());
   return emit_outputs(ctx, zk, pts, pub.data(), proof_buffer, proof_size, public_buffer, public_size, error_msg,
                       error_msg_maxsize, load_ms, zkey_size, cache_hit ? "cached," : "load");
 }
 
 // One-shot: load the key and prove, with the upload overlapped unless ZKPOA_OVERLAP=0. *out_zk <- the loaded key
 // (the caller frees or caches it). load_ms <- time to the end of the proof (load and prove are one phase here).
-int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns,
-                           uint64_t wtns_size, char* proof_buffer, unsigned long* proof_size, char* public_buffer,
+int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zkey_size, const WtnsSrc& wsrc,
+                           char* proof_buffer, unsigned long* proof_size, char* public_buffer,
                            unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize,
                            zkpoa_zkey** out_zk, int zkey_fd = -1) {
   *out_zk = nullptr;
   const char* ov = getenv("ZKPOA_OVERLAP");
   auto tl0 = std::chrono::steady_clock::now();
   if (!ov || strcmp(ov, "0") != 0) {
-    WtnsView w = parse_wtns(wtns, wtns_size);
+    WtnsView w = parse_wtns(wsrc);
     uint8_t rb[32], sb[32], parts[384], header[448], pts[256];
     const uint8_t *rp = nullptr, *sp = nullptr;
     env_blinding(rb, sb, rp, sp);
@@ -1418,15 +1517,17 @@ int load_and_prove_to_json(zkpoa_context* ctx, const uint8_t* zkey, uint64_t zke
       prove_assemble(header, parts, rp, sp, pts);
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       ctx->ms[5] = (float)ms;
-      selfcheck(ctx, zk, pts, w.values + 32);
-      return emit_outputs(ctx, zk, pts, w.values + 32, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+      std::vector<uint8_t> pub_store;
+      const uint8_t* pubs = w.publics(zk->nPublic, pub_store);
+      selfcheck(ctx, zk, pts, pubs);
+      return emit_outputs(ctx, zk, pts, pubs, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                           error_msg_maxsize, ms, zkey_size, "load overlapped with the prove:");
     }
   }
   zkpoa_zkey* zk = zkey_load_impl(ctx, zkey, zkey_size);
   *out_zk = zk;
   const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
-  return prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+  return prove_to_json(ctx, zk, wsrc, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                        error_msg_maxsize, load_ms, zkey_size, false);
 }
 
@@ -1438,20 +1539,21 @@ uint32_t zkey_power(const uint8_t* buf, uint64_t size) {
   return zkey_parse(buf, size, zs)->power;
 }
 
-int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+int one_shot(const uint8_t* zkey, uint64_t zkey_size, const WtnsSrc& wsrc, char* proof_buffer,
              unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
              unsigned long error_msg_maxsize) {
   std::string err;
   DeviceSet* ds = nullptr;
+  int dcode = PROVER_ERROR;
   try {
-    ds = process_devices(zkey_power(zkey, zkey_size), err);
+    ds = process_devices(zkey_power(zkey, zkey_size), err, &dcode);
   } catch (const std::exception& e) {   // malformed key: nothing touches a GPU
     set_err(error_msg, error_msg_maxsize, e.what());
     return PROVER_ERROR;
   }
   if (!ds) {
     set_err(error_msg, error_msg_maxsize, err);
-    return PROVER_ERROR;
+    return dcode;
   }
   zkpoa_context* ctx = ds->ctx[0];
   std::lock_guard<std::mutex> lk(g_prove_mutex);
@@ -1462,10 +1564,10 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const uint8_t* wtns, uint6
     ZK_HIP(hipSetDevice(ctx->dev.device));
     if (ds->ids.size() > 1) {   // one proof over all ranks of the process
       mk = multi_key_load(ds, zkey, zkey_size);
-      rc = multi_prove_to_json(ds, mk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+      rc = multi_prove_to_json(ds, mk, wsrc, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                                error_msg_maxsize, zkey_size, false);
     } else {
-      rc = load_and_prove_to_json(ctx, zkey, zkey_size, wtns, wtns_size, proof_buffer, proof_size, public_buffer,
+      rc = load_and_prove_to_json(ctx, zkey, zkey_size, wsrc, proof_buffer, proof_size, public_buffer,
                                   public_size, error_msg, error_msg_maxsize, &zk);
     }
   } catch (const ProverError& e) {
@@ -1540,7 +1642,7 @@ struct CachedMultiKey {
 };
 std::vector<CachedMultiKey> g_multi_cache;
 
-int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* path, const uint8_t* wtns, uint64_t wtns_size,
+int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* path, const WtnsSrc& wsrc,
                      char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                      char* error_msg, unsigned long error_msg_maxsize) {
   int rc = PROVER_OK;
@@ -1601,7 +1703,7 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
       }
     }
-    rc = multi_prove_to_json(ds, mk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+    rc = multi_prove_to_json(ds, mk, wsrc, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                              error_msg_maxsize, (uint64_t)sb.st_size, hit);
     mk->proofs_done++;
   } catch (const ProverError& e) {
@@ -1610,6 +1712,13 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
   } catch (const HipError& e) {
     set_err(error_msg, error_msg_maxsize, e.what());
     rc = PROVER_ERROR_RUNTIME;
+    // the shards of a key whose proof died in the HIP runtime are not kept for the next request
+    for (size_t i = 0; i < g_multi_cache.size(); i++)
+      if (g_multi_cache[i].mk == mk) {
+        g_multi_cache.erase(g_multi_cache.begin() + (long)i);
+        cached = false;
+        break;
+      }
   } catch (const std::bad_alloc&) {
     set_err(error_msg, error_msg_maxsize, "out of host memory");
     rc = PROVER_ERROR_RUNTIME;
@@ -1624,7 +1733,7 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
   return rc;
 }
 
-int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, char* proof_buffer,
+int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
                     unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg,
                     unsigned long error_msg_maxsize) {
   int fd = open(path, O_RDONLY);
@@ -1640,6 +1749,7 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
   }
   std::string err;
   DeviceSet* ds = nullptr;
+  int dcode = PROVER_ERROR;
   try {
     uint32_t power = 0;
     if (!devices_ready()) {   // the first key of the process decides the device list: its domain size is in the header
@@ -1653,7 +1763,7 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
       }
       munmap(map, (size_t)sb.st_size);
     }
-    ds = process_devices(power, err);
+    ds = process_devices(power, err, &dcode);
   } catch (const std::exception& e) {   // malformed key: nothing touches a GPU
     close(fd);
     set_err(error_msg, error_msg_maxsize, e.what());
@@ -1662,12 +1772,12 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
   if (!ds) {
     close(fd);
     set_err(error_msg, error_msg_maxsize, err);
-    return PROVER_ERROR;
+    return dcode;
   }
   zkpoa_context* ctx = ds->ctx[0];
   std::lock_guard<std::mutex> lk(g_prove_mutex);
   if (ds->ids.size() > 1) {
-    int rc = multi_file_prove(ds, fd, sb, path, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size,
+    int rc = multi_file_prove(ds, fd, sb, path, wsrc, proof_buffer, proof_size, public_buffer, public_size,
                               error_msg, error_msg_maxsize);
     close(fd);
     return rc;
@@ -1699,14 +1809,14 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
         }
         // load and prove in one overlapped phase (the mapping must outlive it: the uploader streams from it)
         try {
-          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
+          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wsrc,
                                       proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
                                       &zk, fd);
         } catch (const HipError&) {
           if (g_key_cache.empty()) throw;
           key_cache_clear();                          // probably out of HBM: retry with nothing else resident
           (void)hipGetLastError();
-          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wtns, wtns_size,
+          rc = load_and_prove_to_json(ctx, reinterpret_cast<const uint8_t*>(map), (uint64_t)sb.st_size, wsrc,
                                       proof_buffer, proof_size, public_buffer, public_size, error_msg, error_msg_maxsize,
                                       &zk, fd);
         }
@@ -1743,7 +1853,7 @@ int zkey_file_prove(const char* path, const uint8_t* wtns, uint64_t wtns_size, c
       }
     }
     if (!proved)
-      rc = prove_to_json(ctx, zk, wtns, wtns_size, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+      rc = prove_to_json(ctx, zk, wsrc, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                          error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
     zk->proofs_done++;
   } catch (const ProverError& e) {
@@ -2044,7 +2154,7 @@ extern "C" int zkpoa_prove(zkpoa_context* ctx, const zkpoa_zkey* zkey, const voi
   try {
     ZK_HIP(hipSetDevice(ctx->dev.device));
     uint8_t dummy[1];
-    prove_impl(ctx, zkey, reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, r_le, s_le, proof_points,
+    prove_impl(ctx, zkey, WtnsSrc{reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, -1}, r_le, s_le, proof_points,
                public_le ? public_le : dummy, public_le ? public_capacity : (zkey->nPublic ? 0 : 1));
   }
   ZK_PROVER_CATCH(ctx)
@@ -2296,6 +2406,11 @@ extern "C" int zkpoa_test_auto_pick_devices(int count, unsigned power, unsigned 
   return (int)ids.size();
 }
 
+// test hook (no GPU): the block size the multi-GPU loader deals sections 5-8 out with (multi_block_log_default)
+extern "C" unsigned zkpoa_test_multi_block_log(uint64_t n_vars, unsigned ranks) {
+  return multi_block_log_default(n_vars, ranks);
+}
+
 extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer,
                               unsigned long wtns_size, char* proof_buffer, unsigned long* proof_size,
                               char* public_buffer, unsigned long* public_size, char* error_msg,
@@ -2305,7 +2420,7 @@ extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, 
     return PROVER_ERROR;
   }
   return one_shot(reinterpret_cast<const uint8_t*>(zkey_buffer), zkey_size,
-                  reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer, proof_size, public_buffer,
+                  WtnsSrc{reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, -1}, proof_buffer, proof_size, public_buffer,
                   public_size, error_msg, error_msg_maxsize);
 }
 
@@ -2316,6 +2431,26 @@ extern "C" int groth16_prover_zkey_file(const char* zkey_file_path, const void* 
     set_err(error_msg, error_msg_maxsize, "null argument");
     return PROVER_ERROR;
   }
-  return zkey_file_prove(zkey_file_path, reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, proof_buffer,
+  return zkey_file_prove(zkey_file_path, WtnsSrc{reinterpret_cast<const uint8_t*>(wtns_buffer), wtns_size, -1}, proof_buffer,
                          proof_size, public_buffer, public_size, error_msg, error_msg_maxsize);
+}
+
+extern "C" int zkpoa_groth16_prover_files(const char* zkey_file_path, const char* wtns_file_path, char* proof_buffer,
+                                          unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
+                                          char* error_msg, unsigned long error_msg_maxsize) {
+  if (!zkey_file_path || !wtns_file_path || !proof_size || !public_size) {
+    set_err(error_msg, error_msg_maxsize, "null argument");
+    return PROVER_ERROR;
+  }
+  int wfd = open(wtns_file_path, O_RDONLY | O_CLOEXEC);
+  struct stat wsb;
+  if (wfd < 0 || fstat(wfd, &wsb) != 0 || !S_ISREG(wsb.st_mode)) {
+    if (wfd >= 0) close(wfd);
+    set_err(error_msg, error_msg_maxsize, std::string("cannot read witness file ") + wtns_file_path);
+    return PROVER_ERROR;
+  }
+  int rc = zkey_file_prove(zkey_file_path, WtnsSrc{nullptr, (uint64_t)wsb.st_size, wfd}, proof_buffer, proof_size,
+                           public_buffer, public_size, error_msg, error_msg_maxsize);
+  close(wfd);
+  return rc;
 }

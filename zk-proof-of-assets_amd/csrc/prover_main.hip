@@ -14,6 +14,7 @@
 // The socket lives in a 0700 directory of the calling user and the server checks the peer's uid.
 #include "../../include/zkpoa_prover.h"
 
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <limits.h>
@@ -34,31 +35,34 @@
 #include <string>
 #include <vector>
 
-// read-only mapping of a whole file (the witness: 67 MB at layer one, 1.7 GB at layer three); the library's
-// uploader copies from it straight into its pinned staging buffers, so the file is never copied on the host
-struct MappedFile {
-  void* p = nullptr;
-  size_t size = 0;
-  bool open_file(const char* path) {
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return false;
-    struct stat sb;
-    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
-      close(fd);
-      return false;
-    }
-    size = (size_t)sb.st_size;
-    if (size) {
-      p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-      if (p == MAP_FAILED) p = nullptr;
-    }
-    close(fd);
-    return size == 0 || p != nullptr;
+// The library is loaded on demand (dlopen): a client of the resident server never proves itself, and resolving
+// libzkpoa_prover.so with the HIP runtime behind it costs ~11 ms of every call (measured r04: 28 ms per layer-one
+// proof through the server, of which 15 in the server). Looked for next to this executable, then on the usual path.
+typedef int (*prover_files_fn)(const char*, const char*, char*, unsigned long*, char*, unsigned long*, char*, unsigned long);
+static prover_files_fn load_prover(std::string& message) {
+  static prover_files_fn fn = nullptr;
+  if (fn) return fn;
+  std::string tried;
+  char exe[PATH_MAX];
+  ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+  void* h = nullptr;
+  if (n > 0) {
+    exe[n] = 0;
+    std::string dir(exe);
+    dir = dir.substr(0, dir.rfind('/'));
+    h = dlopen((dir + "/libzkpoa_prover.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) tried = dlerror();
   }
-  ~MappedFile() {
-    if (p) munmap(p, size);
+  if (!h) h = dlopen("libzkpoa_prover.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    message = std::string("Error: cannot load libzkpoa_prover.so (") + (tried.empty() ? dlerror() : tried.c_str()) +
+              "); the prover has no CPU fallback";
+    return nullptr;
   }
-};
+  fn = reinterpret_cast<prover_files_fn>(dlsym(h, "zkpoa_groth16_prover_files"));
+  if (!fn) message = "Error: libzkpoa_prover.so does not export zkpoa_groth16_prover_files";
+  return fn;
+}
 
 static bool write_atomic(const char* path, const char* text) {
   std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
@@ -85,26 +89,26 @@ static double now_ms() {
 // not from the inputs: the process's GPU context cannot be trusted any more.
 static int prove_files(const char* zkey, const char* wtns_path, const char* proof_path, const char* public_path,
                        std::string& message, bool* runtime_failure = nullptr) {
-  MappedFile wtns;
-  const double t_map = now_ms();
-  if (!wtns.open_file(wtns_path)) {
-    message = std::string("Error: cannot read witness file ") + wtns_path;
-    return EXIT_FAILURE;
+  prover_files_fn prover = load_prover(message);
+  if (!prover) return EXIT_FAILURE;
+  {   // an unreadable witness is reported before the GPU is touched, in the words the reference's tests look for
+    int fd = open(wtns_path, O_RDONLY | O_CLOEXEC);
+    struct stat sb;
+    const bool ok = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    if (fd >= 0) close(fd);
+    if (!ok) {
+      message = std::string("Error: cannot read witness file ") + wtns_path;
+      return EXIT_FAILURE;
+    }
   }
-  if (getenv("ZKPOA_VERBOSE"))
-    fprintf(stderr, "zkpoa: witness file mapped (%.1f MB) in %.2f ms\n", wtns.size / 1e6, now_ms() - t_map);
-  static const char kEmpty[1] = {0};
-  const void* wtns_data = wtns.p ? wtns.p : kEmpty;
   unsigned long proof_size = 1 << 12, public_size = 1 << 16;
   std::vector<char> proof(proof_size), pub(public_size);
   char err[1024] = {0};
-  int rc = groth16_prover_zkey_file(zkey, wtns_data, wtns.size, proof.data(), &proof_size, pub.data(),
-                                    &public_size, err, sizeof(err));
+  int rc = prover(zkey, wtns_path, proof.data(), &proof_size, pub.data(), &public_size, err, sizeof(err));
   if (rc == PROVER_ERROR_SHORT_BUFFER) {
     proof.resize(proof_size);
     pub.resize(public_size);
-    rc = groth16_prover_zkey_file(zkey, wtns_data, wtns.size, proof.data(), &proof_size, pub.data(), &public_size,
-                                  err, sizeof(err));
+    rc = prover(zkey, wtns_path, proof.data(), &proof_size, pub.data(), &public_size, err, sizeof(err));
   }
   if (rc != PROVER_OK) {
     message = std::string("Error: ") + err;
@@ -223,6 +227,15 @@ static bool secure_dir(const std::string& sock) {
   return (sb.st_mode & 0077) == 0 || getenv("ZKPOA_SERVER")[0] == '/';   // an explicit path is the caller's choice
 }
 
+// pid of the server behind a connected socket, taken from the kernel (SO_PEERCRED: the credentials of the process that
+// listens), or 0 when the peer is not a process of this user -- the only identity a client ever acts on
+static long peer_server_pid(int fd) {
+  struct ucred cred;
+  socklen_t cl = sizeof(cred);
+  if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cred, &cl) != 0 || cred.uid != getuid()) return 0;
+  return (long)cred.pid;
+}
+
 static int connect_to(const std::string& sock) {
   int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
   if (fd < 0) return -1;
@@ -251,10 +264,7 @@ static int server_main(const std::string& sock) {
   std::string lockp = sock + ".lock";
   int lock = open(lockp.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
   if (lock < 0 || flock(lock, LOCK_EX | LOCK_NB) != 0) return 0;   // another server owns this socket
-  {   // our pid, for a client that has to end a wedged server (kept in the lock file: only its holder writes it)
-    const std::string pid = std::to_string((long)getpid()) + "\n";
-    if (ftruncate(lock, 0) == 0) (void)!pwrite(lock, pid.data(), pid.size(), 0);
-  }
+  // (the lock file carries no pid: a client identifies the server by the kernel's SO_PEERCRED of its own connection)
   unlink(sock.c_str());                                           // stale socket of a dead server
   int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
   struct sockaddr_un sa;
@@ -311,7 +321,8 @@ static int server_main(const std::string& sock) {
         set_or_clear("ZKPOA_VERBOSE", f[8]);   // the library's phase line goes to <socket>.log
         const double t0 = now_ms();
         std::string message;
-        if (getenv("ZKPOA_SERVER_TEST_CRASH")) _exit(3);   // tests: the server dies with a request in hand
+        static const bool test_crash = getenv("ZKPOA_SERVER_TEST_CRASH") != nullptr;   // read once, at the first request
+        if (test_crash) _exit(3);                        // tests: the server dies with a request in hand
         bool runtime_failure = false;
         int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message, &runtime_failure);
         if (rc == EXIT_SUCCESS && !f[8].empty())
@@ -328,12 +339,19 @@ static int server_main(const std::string& sock) {
       } else {
         reply = "1Error: malformed request to the prover server";
       }
+      if (!running) {   // leaving: the socket disappears BEFORE the answer goes out, so that the caller's next request
+        unlink(sock.c_str());   // finds no socket and starts a fresh server instead of queueing behind one that is gone
+        close(ls);
+        ls = -1;
+      }
       send_msg(c, reply);
     }
     close(c);
   }
-  close(ls);
-  unlink(sock.c_str());
+  if (ls >= 0) {
+    unlink(sock.c_str());
+    close(ls);
+  }
   close(lock);
   if (exit_code) _exit(exit_code);   // no HIP teardown on a context that has already failed
   return 0;
@@ -348,14 +366,16 @@ static std::string abs_path(const char* p) {
 
 // Client side. Returns the exit code, or -1 when no server could be reached (the caller proves in-process).
 static int client_main(char** argv, const std::string& sock, bool stop) {
+  // the directory is checked BEFORE anything in it is trusted: a socket somebody else planted in a directory they own
+  // is never connected to, and no lock file of theirs is ever read
+  if (!secure_dir(sock)) {
+    if (stop) return EXIT_SUCCESS;
+    fprintf(stderr, "zkpoa: server socket directory of %s is not private to this user; proving in-process\n", sock.c_str());
+    return -1;
+  }
   int fd = connect_to(sock);
   if (fd < 0 && stop) return EXIT_SUCCESS;   // nothing to stop
   if (fd < 0) {
-    if (!secure_dir(sock)) {
-      fprintf(stderr, "zkpoa: server socket directory of %s is not private to this user; proving in-process\n",
-              sock.c_str());
-      return -1;
-    }
     // start the server: a detached child of this (GPU-free) process
     pid_t pid = fork();
     if (pid == 0) {
@@ -377,6 +397,13 @@ static int client_main(char** argv, const std::string& sock, bool stop) {
       fd = connect_to(sock);
     }
     if (fd < 0) return -1;
+  }
+  const long spid = peer_server_pid(fd);   // the process that listens on THIS connection, same uid -- or nobody
+  if (spid == 0) {
+    close(fd);
+    if (stop) return EXIT_SUCCESS;
+    fprintf(stderr, "zkpoa: the process behind %s is not a prover server of this user; proving in-process\n", sock.c_str());
+    return -1;
   }
   std::string req;
   if (stop) {
@@ -405,21 +432,31 @@ static int client_main(char** argv, const std::string& sock, bool stop) {
     const bool timed_out = errno == EAGAIN || errno == EWOULDBLOCK;
     close(fd);
     if (stop) return EXIT_SUCCESS;
-    // A server that is still alive here is wedged (or was leaving): it may hold tens of GB of cached keys in HBM and may
-    // still be writing the same output paths. End it -- the pid it left in its lock file, same uid -- before this
-    // process takes the GPU. Never a re-exec: this process proves itself, a later call starts a fresh server.
-    long spid = 0;
-    if (FILE* lf = fopen((sock + ".lock").c_str(), "r")) {
-      if (fscanf(lf, "%ld", &spid) != 1) spid = 0;
-      fclose(lf);
-    }
-    bool killed = false;
-    if (spid > 1 && spid != (long)getpid() && kill((pid_t)spid, 0) == 0) {
-      killed = kill((pid_t)spid, SIGKILL) == 0;
-      for (int i = 0; killed && i < 100 && kill((pid_t)spid, 0) == 0; i++) usleep(20000);
+    // The server is left alone by default. The single-threaded server serves one client at a time, so a client that
+    // timed out may simply have been queued behind other long proofs -- killing the server then would take down a
+    // healthy process in the middle of somebody else's proof; and a server that closed the connection is either gone or
+    // running its loop, not wedged. Only with ZKPOA_SERVER_KILL_WEDGED=1, only after a timeout, only the pid the kernel
+    // reported for this very connection (SO_PEERCRED, same uid) and only while the server's lock is still held (the
+    // process that took it is still the one that listens) is the server ended -- it may hold tens of GB of cached keys
+    // in HBM. Never a re-exec: this process proves itself, a later call starts a fresh server.
+    bool killed = false, alive = kill((pid_t)spid, 0) == 0;
+    const char* kw = getenv("ZKPOA_SERVER_KILL_WEDGED");
+    if (timed_out && alive && kw && !strcmp(kw, "1") && spid > 1 && spid != (long)getpid()) {
+      int lf = open((sock + ".lock").c_str(), O_RDWR | O_CLOEXEC | O_NOFOLLOW);
+      bool held = false;
+      if (lf >= 0) {
+        held = flock(lf, LOCK_EX | LOCK_NB) != 0;   // we could take it: no server owns the socket any more
+        if (!held) flock(lf, LOCK_UN);
+        close(lf);
+      }
+      if (held) {
+        killed = kill((pid_t)spid, SIGKILL) == 0;
+        for (int i = 0; killed && i < 100 && kill((pid_t)spid, 0) == 0; i++) usleep(20000);
+      }
     }
     log_fault(timed_out ? "prover server did not answer in time" : "prover server went away without answering",
-              std::string("server pid ") + std::to_string(spid) + (killed ? " (killed)" : " (gone)"), argv[1]);
+              std::string("server pid ") + std::to_string(spid) + (killed ? " (killed)" : alive ? " (left running)" : " (gone)"),
+              argv[1]);
     if (strict_mode()) {
       fprintf(stderr, "zkpoa: the prover server went away without answering; ZKPOA_STRICT is set: not proving in-process\n");
       return kExitStrict;

@@ -82,6 +82,15 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
     ctx->opt_prove_serial = value != 0;
     return PROVER_OK;
   }
+  if (!strcmp(key, "scan_poll_limit_log2")) {   // polls of one status word before a scan look-back gives up (default 24)
+    if (value < 4 || value > 30) return PROVER_ERROR;
+    for (auto& l : ctx->dev.lanes) l.scan_poll_limit = 1u << value;
+    return PROVER_OK;
+  }
+  if (!strcmp(key, "scan_test_withhold")) {     // tests only: tile 0 of every scan withholds its prefix
+    for (auto& l : ctx->dev.lanes) l.scan_test_withhold = value != 0;
+    return PROVER_OK;
+  }
   ctx->last_error = std::string("unknown option ") + key;
   return PROVER_ERROR;
 }
