@@ -115,3 +115,39 @@ def test_prove_layer_three_shape_all_points(ctx, zk):
 def test_prove_2p26_all_points(ctx, zk):
     """BASELINE.json configs[4], N = 1: synthetic layer_one(128 sigs) shape (tests/old/128_sigs/benchmarks.txt:4-10)."""
     _prove_and_check_all(ctx, zk, 26, 61197000, 1, 0x5EED0010, oracle_h=False)
+
+
+def test_layer_one_shape_through_the_file_boundary_on_several_ranks_vs_c_oracle(ctx, zk, tmp_path):
+    """BASELINE.json configs[3], layer-one leg, through the boundary the reference really has
+    (scripts/g16_prove.sh:248-252 execs `prover <zkey> <wtns> <proof.json> <public.json>`; one such process per batch,
+    scripts/full_workflow.sh:552): the L1(2 sigs) shape -- n = 2^21, 2,083,343 wires -- written as a real 1.08 GB .zkey and
+    a 67 MB .wtns, proved by the executable on 1, 2 and 4 ranks (ZKPOA_DEVICES: real block-cyclic shards of 2^16 / 2^15
+    wires read from the file's byte ranges, cyclic section 9, split chain with its two exchanges, the witness uploaded
+    in slices). Every proof.json must hold exactly the points the C ORACLE's orc_prove computes from the same two files
+    (~8 s on 16 host threads), and public.json its public signal."""
+    import subprocess
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    zp, wp = str(tmp_path / "circuit_final.zkey"), str(tmp_path / "witness.wtns")
+    circ = SyntheticCircuit(zk, ctx, 21, 2083343, n_public=1, seed=0x5EED0021, witness_like=True)
+    try:
+        circ.write_zkey(zp)
+        circ.write_wtns(wp)
+    finally:
+        circ.close()
+    r_, s_ = 0x1234567890abcdef1234567, 0xfedcba0987654321
+    t0 = time.time()
+    want_pts, want_pub = co.prove(open(zp, "rb").read(), open(wp, "rb").read(), r_, s_, THREADS, n_public=1)
+    t_cpu = time.time() - t0
+    want = zk.proof_to_json(want_pts, "rapidsnark")
+    base = dict(os.environ, ZKPOA_R=str(r_), ZKPOA_S=str(s_), ZKPOA_VERBOSE="1", ZKPOA_SELFCHECK="0")   # no valid vkey inside
+    base.pop("ZKPOA_SERVER", None)
+    for devices in ("0", "0,0", "0,0,0,0"):
+        out = str(tmp_path / ("proof_%d.json" % len(devices)))
+        rc = subprocess.run([zk.PROVER_BIN, zp, wp, out, str(tmp_path / "public.json")],
+                            env=dict(base, ZKPOA_DEVICES=devices), capture_output=True, text=True, timeout=600)
+        assert rc.returncode == 0, rc.stderr
+        assert open(out).read() == want, "ranks %s: proof differs from the C oracle's" % devices
+        assert open(tmp_path / "public.json").read() == zk.public_to_json(want_pub, "rapidsnark")
+        if "," in devices:
+            assert "H-scalar chain split" in rc.stderr and "block-cyclic" in rc.stderr
+    print("L1 shape through the file boundary on 1 / 2 / 4 ranks == C oracle (orc_prove %.1f s on %d threads)" % (t_cpu, THREADS))

@@ -871,6 +871,42 @@ def test_multi_process_sharded_prove_rehearsal(nproc, extra):
     assert line["n_ranks_seen"] == nproc
 
 
+def test_bench_lines_carry_the_same_curves_at_every_n():
+    """the driver plots bench.py's default line over N. Its `value` is the headline of that N (the
+    2^20 MSM at N = 1, ONE 2^26 proof over the GPUs at N > 1), so every default line also carries the two curves of
+    BASELINE.json's metric under the SAME keys: `curve` (strong: proofs/s of the one proof) and `curve_weak` (pts/s of the
+    per-GPU MSM). Checked on the default code path with test-size workloads (ZKPOA_BENCH_SMALL=1): N = 1, and N = 2 as
+    the driver launches it (rehearsal: ranks share the GPU)."""
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for nproc in (1, 2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, ZKPOA_BENCH_SMALL="1")
+        tail = [os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        if nproc == 1:
+            argv = [sys.executable] + tail
+        else:
+            env["ZKPOA_BENCH_REHEARSE"] = "1"
+            argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                    "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+        rc = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        lines[nproc] = json.loads([l for l in rc.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert one["metric"] == "G1-MSM throughput" and two["metric"] == "Groth16 proofs/sec"      # headlines differ ...
+    for key, scaling, unit in (("curve", "strong", "proofs/s"), ("curve_weak", "weak", "pts/s")):
+        a, b = one[key], two[key]                                                                 # ... the curves do not
+        assert set(a) == set(b) == {"workload", "value", "unit", "scaling", "ms_per_step", "n_gpus"}
+        assert a["workload"] == b["workload"] and a["unit"] == b["unit"] == unit and a["scaling"] == b["scaling"] == scaling
+        assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and a["value"] > 0 and b["value"] > 0
+    assert one["curve_weak"]["value"] == one["value"] and two["curve"]["value"] == two["value"]
+
+
 def test_bench_collectives_over_rccl_with_one_rank():
     """The N > 1 code path of bench.py over the REAL RCCL backend, as far as one GPU allows: ZKPOA_BENCH_FORCE_DIST=1
     initialises the nccl process group with a single rank and sends the MSM partials, the timing reduction, the pass /

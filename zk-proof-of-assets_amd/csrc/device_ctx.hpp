@@ -131,6 +131,7 @@ struct DeviceCtx {
   // with the MSMs). First thing the background thread creates; copy_stream_wait() blocks until it exists.
   hipStream_t copy_stream = nullptr;
   std::function<void(hipStream_t)> after_copy_stream;   // runs on the background thread once the copy stream exists
+  std::function<void()> after_lanes;                    // runs on the background thread once every eager lane is up
   std::mutex copy_mutex_;
   std::condition_variable copy_cv_;
   bool copy_done_ = false;
@@ -187,6 +188,12 @@ struct DeviceCtx {
         static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1}, kTop1[6] = {2, 1, 1, 0, 0, 0};
         for (int i = 1; i < kEagerLanes; i++)
           lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : top1 ? kTop1[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
+        if (after_lanes) {
+          try {
+            after_lanes();
+          } catch (...) {   // extras only
+          }
+        }
       } catch (...) {
         bg_err_ = std::current_exception();
         {

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -54,7 +55,11 @@ class FastUploader {
         try {
           ZK_HIP(hipSetDevice(device));
           Slot& s = slots_[t];
-          hipStream_t st = own_streams_.empty() ? stream : own_streams_[t % own_streams_.size()];
+          // streams: the caller's plus the uploader's own, as many as exist by now (they come up in the background);
+          // one stream -- one SDMA queue -- moves ~36 GB/s whatever the thread count, four reach the link's ~53 GB/s
+          const int ns = n_own_.load(std::memory_order_acquire);
+          const int pick = t % (ns + 1);
+          hipStream_t st = pick == ns ? stream : own_[pick];
           int b = 0;
           for (size_t off = lo; off < hi; off += kChunk, b ^= 1) {
             size_t len = hi - off < kChunk ? hi - off : kChunk;
@@ -75,6 +80,25 @@ class FastUploader {
       if (e) std::rethrow_exception(e);
   }
 
+  // Streams of the uploader's own (ZKPOA_UPLOAD_STREAMS, default 3: four with the caller's). Called from the context's
+  // background thread AFTER the lanes are up: a stream costs 10-50 ms to create, so a one-shot prover's first upload
+  // (the witness) starts on the caller's stream alone and later sections find more streams as they appear.
+  void add_streams(int device) {
+    int want = 3;
+    if (const char* e = getenv("ZKPOA_UPLOAD_STREAMS")) want = atoi(e);
+    if (want > kMaxOwnStreams) want = kMaxOwnStreams;
+    for (int i = n_own_.load(); i < want; i++) {
+      if (hipSetDevice(device) != hipSuccess) return;
+      hipStream_t st = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+      }
+      own_[i] = st;
+      n_own_.store(i + 1, std::memory_order_release);
+    }
+  }
+
   // pin the staging buffers ahead of the first upload (a one-shot prover: on the context's background thread)
   void prepare(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(ensure_mutex_);
@@ -89,8 +113,8 @@ class FastUploader {
         s.done[b] = nullptr;
       }
     }
-    for (hipStream_t st : own_streams_) (void)hipStreamDestroy(st);
-    own_streams_.clear();
+    const int ns = n_own_.exchange(0);
+    for (int i = 0; i < ns; i++) (void)hipStreamDestroy(own_[i]);
     if (block_) (void)hipHostFree(block_);
     block_ = nullptr;
     ready_ = false;
@@ -105,7 +129,9 @@ class FastUploader {
   void* block_ = nullptr;
   bool ready_ = false;
   int threads_ = 8;
-  std::vector<hipStream_t> own_streams_;   // ZKPOA_UPLOAD_STREAMS > 0 (experiments): copies spread over that many streams
+  static constexpr int kMaxOwnStreams = 8;
+  hipStream_t own_[kMaxOwnStreams] = {};
+  std::atomic<int> n_own_{0};
 
   static void read_all(int fd, char* out, size_t len, uint64_t pos) {
     size_t got = 0;
@@ -132,14 +158,6 @@ class FastUploader {
     unsigned hw = std::thread::hardware_concurrency();
     if (hw && (int)hw < threads_) threads_ = (int)hw;
     ZK_HIP(hipSetDevice(device));
-    if (const char* e = getenv("ZKPOA_UPLOAD_STREAMS")) {
-      const int v = atoi(e);
-      for (int i = 0; i < v && i < kMaxThreads; i++) {
-        hipStream_t st = nullptr;
-        ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        own_streams_.push_back(st);
-      }
-    }
     ZK_HIP(hipHostMalloc(&block_, (size_t)threads_ * 2 * kChunk, hipHostMallocDefault));   // one pinning call
     for (int t = 0; t < threads_; t++) {
       Slot& s = slots_[t];

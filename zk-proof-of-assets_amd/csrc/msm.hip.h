@@ -326,6 +326,11 @@ struct ScanPair {
   uint32_t* out_b;
   uint32_t* total_b;
   uint32_t* max_out;    // optional: atomicMax of the raw inputs
+  // optional: histogram of the level-0 piece lengths the raw inputs (bucket counts) imply -- a bucket of x entries is
+  // x / hist_K pieces of hist_K entries and one of x % hist_K: hist[len] += pieces of that length (len <= hist_K <= 512).
+  // The piece-ordering kernel needs it complete before it runs, and the scan reads every bucket count anyway.
+  uint32_t* hist = nullptr;
+  uint32_t hist_K = 0;
 };
 
 ZK_DEV uint64_t scan_status_load(const uint64_t* p) {
@@ -398,7 +403,10 @@ static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a
                                                                       uint32_t ntiles, ScanGuard guard) {
   __shared__ uint32_t lds[8];
   __shared__ uint32_t s_tile, s_pre_a, s_pre_b;
+  __shared__ uint32_t s_hist[kMaxPieceLenPlan + 1];
   if (threadIdx.x == 0) s_tile = atomicAdd(&tickets[0], 1u);
+  if (a.hist)
+    for (uint32_t i = threadIdx.x; i <= a.hist_K; i += kScanBlock) s_hist[i] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
   const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
@@ -411,6 +419,11 @@ static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a
     va[k] = scan_input(a.in, base + k, a.n, a.mode_a, a.K_a, raw);
     sum_a += va[k];
     mx = raw > mx ? raw : mx;
+    if (a.hist && raw) {
+      const uint32_t full = raw / a.hist_K, rem = raw - full * a.hist_K;
+      if (full) atomicAdd(&s_hist[a.hist_K], full);
+      if (rem) atomicAdd(&s_hist[rem], 1u);
+    }
     vb[k] = 0;
     if (two) {
       if (a.mode_b == 0) vb[k] = raw;
@@ -458,6 +471,12 @@ static __global__ __launch_bounds__(kScanBlock) void scan_pair_kernel(ScanPair a
       mx = y > mx ? y : mx;
     }
     if ((threadIdx.x & 63u) == 0 && mx) atomicMax(a.max_out, mx);
+  }
+  if (a.hist) {   // (the barrier of the block scans above has ordered every LDS atomic before this)
+    for (uint32_t i = threadIdx.x; i <= a.hist_K; i += kScanBlock) {
+      const uint32_t c = s_hist[i];
+      if (c) atomicAdd(&a.hist[i], c);
+    }
   }
   // rewind the tickets for the next call (stream order: it cannot start before this grid has drained)
   if (threadIdx.x == 0 && atomicAdd(&tickets[1], 1u) == ntiles - 1) {
@@ -542,42 +561,40 @@ namespace zkpoa {
 // longest first.
 constexpr uint32_t kMaxPieceLen = 512;
 
-// pass 1: piece t -> (bucket, length); histogram of lengths
-static __global__ __launch_bounds__(256) void msm_piece_len_kernel(const uint32_t* __restrict__ cnt0,
-                                                                   const uint32_t* __restrict__ po1, uint32_t TB,
-                                                                   uint32_t K0, uint32_t* __restrict__ pbkt,
-                                                                   uint32_t* __restrict__ plen,
-                                                                   uint32_t* __restrict__ len_hist) {
+// order[pos] = t with the pieces sorted by descending length, pbkt[t] = the piece's bucket. The histogram of the
+// lengths comes from the scan that produced the piece offsets (ScanPair::hist). Every thread takes kPiecesPerThread
+// pieces (r03 took one, in two kernels: 100 k workgroups of a 2^26 MSM each reserved its slice of ~64 length classes
+// with one global atomic per class -- 6 M atomics on 64 addresses, 4.1 ms of an 87 ms MSM -- and the bucket of every
+// piece was searched twice).
+constexpr uint32_t kPiecesPerThread = 8;
+// the piece-length histogram on its own (the three-launch scans of ZKPOA_SCAN=3 do not carry it)
+static __global__ __launch_bounds__(256) void msm_piece_hist_kernel(const uint32_t* __restrict__ cnt0, uint32_t TB,
+                                                                    uint32_t K0, uint32_t* __restrict__ len_hist) {
   __shared__ uint32_t h[kMaxPieceLen + 1];
-  for (uint32_t i = threadIdx.x; i <= kMaxPieceLen; i += 256u) h[i] = 0;
+  for (uint32_t i = threadIdx.x; i <= K0; i += 256u) h[i] = 0;
   __syncthreads();
-  uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  uint32_t total = po1[TB];
-  if (t < total) {
-    uint32_t b = find_bucket(po1, TB, t);
-    uint32_t j = t - po1[b];
-    uint32_t len = cnt0[b] - j * K0;
-    if (len > K0) len = K0;
-    pbkt[t] = b;
-    plen[t] = len;
-    atomicAdd(&h[len], 1u);
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t x = b < TB ? cnt0[b] : 0u;
+  if (x) {
+    const uint32_t full = x / K0, rem = x - full * K0;
+    if (full) atomicAdd(&h[K0], full);
+    if (rem) atomicAdd(&h[rem], 1u);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= kMaxPieceLen; i += 256u)
+  for (uint32_t i = threadIdx.x; i <= K0; i += 256u)
     if (h[i]) atomicAdd(&len_hist[i], h[i]);
 }
-
-// pass 2: order[pos] = t with pieces sorted by descending length
-static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint32_t* __restrict__ plen,
+static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint32_t* __restrict__ cnt0,
                                                                      const uint32_t* __restrict__ po1, uint32_t TB,
-                                                                     const uint32_t* __restrict__ len_hist,
+                                                                     uint32_t K0, const uint32_t* __restrict__ len_hist,
                                                                      uint32_t* __restrict__ cursor,
+                                                                     uint32_t* __restrict__ pbkt,
                                                                      uint32_t* __restrict__ order) {
   __shared__ uint32_t base[kMaxPieceLen + 2];   // start of each length class in descending order
   __shared__ uint32_t h[kMaxPieceLen + 1];      // local count, then reserved global start
   __shared__ uint32_t wsum[4];
   // descending exclusive prefix over lengths: base[L] = sum_{l > L} hist[l]
-  // (513 entries: two per thread, block scan over reversed index)
+  // (513 entries: three per thread, block scan over reversed index)
   uint32_t tid = threadIdx.x;
   uint32_t v0 = 0, v1 = 0, v2 = 0;
   uint32_t r0 = 3 * tid, r1 = 3 * tid + 1, r2 = 3 * tid + 2;   // reversed positions: length = kMax - r
@@ -591,13 +608,22 @@ static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint3
   if (r2 <= kMaxPieceLen) base[kMaxPieceLen - r2] = ex + v0 + v1;
   for (uint32_t i = tid; i <= kMaxPieceLen; i += 256u) h[i] = 0;
   __syncthreads();
-  uint32_t t = blockIdx.x * 256u + tid;
-  uint32_t total = po1[TB];
-  uint32_t len = 0, local = 0;
-  bool valid = t < total;
-  if (valid) {
-    len = plen[t];
-    local = atomicAdd(&h[len], 1u);
+  const uint32_t total = po1[TB];
+  uint32_t len[kPiecesPerThread], local[kPiecesPerThread];
+#pragma unroll
+  for (uint32_t k = 0; k < kPiecesPerThread; k++) {
+    const uint32_t t = (blockIdx.x * kPiecesPerThread + k) * 256u + tid;
+    len[k] = 0;
+    local[k] = 0;
+    if (t < total) {
+      const uint32_t b = find_bucket(po1, TB, t);
+      const uint32_t j = t - po1[b];
+      uint32_t l = cnt0[b] - j * K0;
+      if (l > K0) l = K0;
+      pbkt[t] = b;
+      len[k] = l;
+      local[k] = atomicAdd(&h[l], 1u);
+    }
   }
   __syncthreads();
   for (uint32_t i = tid; i <= kMaxPieceLen; i += 256u) {
@@ -605,7 +631,11 @@ static __global__ __launch_bounds__(256) void msm_piece_order_kernel(const uint3
     if (c) h[i] = atomicAdd(&cursor[i], c);
   }
   __syncthreads();
-  if (valid) order[base[len] + h[len] + local] = t;
+#pragma unroll
+  for (uint32_t k = 0; k < kPiecesPerThread; k++) {
+    const uint32_t t = (blockIdx.x * kPiecesPerThread + k) * 256u + tid;
+    if (t < total) order[base[len[k]] + h[len[k]] + local[k]] = t;
+  }
 }
 
 // waves per SIMD the accumulation kernel is compiled for (register budget 512 / waves):
@@ -738,7 +768,8 @@ inline uint32_t msm_reduce_log_parts(uint32_t logRows, uint32_t logS = 0, uint32
 inline uint32_t msm_reduce_bits(uint32_t logS) { return logS + 1; }   // column weights go up to S = 2^logS
 
 template <class F>
-static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void* __restrict__ buckets, uint32_t W,
+static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void* __restrict__ buckets,
+                                                                     const uint32_t* __restrict__ counts, uint32_t W,
                                                                      uint32_t Nb, uint32_t logS, uint32_t logRows,
                                                                      uint32_t logParts, uint32_t E,
                                                                      void* __restrict__ out) {
@@ -761,7 +792,11 @@ static __global__ __launch_bounds__(256) void msm_bucket_sums_kernel(const void*
   for (uint32_t it = 0; it < per_max + logParts; it++) {
     XYZZ<F> other = XYZZ<F>::inf();
     if (it < per_max) {
-      if (valid && it < per) other = load_xyzz<F>(buckets, base + (size_t)(part * per + it) * stride);
+      // an empty bucket was never written (the array is not cleared: 3.2 GB per 2^26 MSM): its count says so
+      if (valid && it < per) {
+        const size_t bi = base + (size_t)(part * per + it) * stride;
+        if (counts[bi]) other = load_xyzz<F>(buckets, bi);
+      }
     } else {
       const uint32_t st = parts >> (it - per_max + 1u);
       store_xyzz(lds_raw, threadIdx.x, acc);
@@ -888,7 +923,7 @@ inline size_t msm_sort_workspace_bytes(const MsmPlan& p) {
   }
   bytes += al256(((size_t)p.TB / kScanTile + 2) * 4);
   bytes += al256(64);
-  bytes += al256(p1 * 4) * 3;                        // pbkt, plen, order
+  bytes += al256(p1 * 4) * 2;                        // pbkt, order
   bytes += al256((kMaxPieceLen + 1) * 4 * 2);        // len_hist, cursor
   return bytes + (1 << 12);
 }
@@ -941,17 +976,25 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   ws.reset();
   const size_t T_max = (size_t)p.n * p.W;
   const SortPlan sp = make_sort_plan(p.ne, p.Wb, p.c);
+  // everything that must start at zero sits in ONE block at the head of the arena and is cleared by one memset (r03:
+  // four, each a launch of its own on a lane whose MSM is ~45 launches): bucket counts, the segment counts of the
+  // intermediate passes, the misc words, the piece-length histogram and its cursors
+  char* zero_lo = ws.base + ws.off;
   sr.counts = ws.take<uint32_t>(p.TB);
+  uint32_t* seg_cnt[kSortMaxPasses] = {};
+  for (uint32_t l = 0; l + 1 < sp.npass; l++) seg_cnt[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
+  uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
+  uint32_t* len_hist = ws.take<uint32_t>(2 * (kMaxPieceLen + 1));
+  uint32_t* len_cursor = len_hist + (kMaxPieceLen + 1);
+  const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_lo);
   sr.off0 = ws.take<uint32_t>(p.TB + 1);
   sr.po_a = ws.take<uint32_t>(p.TB + 1);
   uint32_t* digits = ws.take<uint32_t>(T_max);
   uint2* ebuf[2] = {sp.npass > 1 ? ws.take<uint2>(T_max) : nullptr, sp.npass > 2 ? ws.take<uint2>(T_max) : nullptr};
   // per pass: output segment counts / offsets / task offsets (the last pass writes the bucket arrays) and bases
-  uint32_t *seg_cnt[kSortMaxPasses] = {}, *seg_off[kSortMaxPasses] = {}, *seg_tpo[kSortMaxPasses] = {},
-           *base[kSortMaxPasses] = {};
+  uint32_t *seg_off[kSortMaxPasses] = {}, *seg_tpo[kSortMaxPasses] = {}, *base[kSortMaxPasses] = {};
   for (uint32_t l = 0; l < sp.npass; l++) {
     if (l + 1 < sp.npass) {
-      seg_cnt[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
       seg_off[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
       seg_tpo[l] = ws.take<uint32_t>(sp.segs[l + 1] + 1);
     }
@@ -959,19 +1002,11 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   }
   sr.sorted = ws.take<uint32_t>(T_max);
   uint32_t* block_sums = ws.take<uint32_t>(p.TB / kScanTile + 2);
-  uint32_t* misc = ws.take<uint32_t>(16);  // [0]=T, [1]=max count, [2]=total pieces, ...
   size_t p1_cap = T_max / p.K0 + p.TB + 1;
   sr.pbkt = ws.take<uint32_t>(p1_cap);
-  uint32_t* plen = ws.take<uint32_t>(p1_cap);
   sr.order = ws.take<uint32_t>(p1_cap);
-  uint32_t* len_hist = ws.take<uint32_t>(2 * (kMaxPieceLen + 1));
-  uint32_t* len_cursor = len_hist + (kMaxPieceLen + 1);
 
-  ZK_HIP(hipMemsetAsync(sr.counts, 0, (size_t)p.TB * 4, st));
-  ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
-  ZK_HIP(hipMemsetAsync(len_hist, 0, 2 * (kMaxPieceLen + 1) * 4, st));
-  for (uint32_t l = 0; l + 1 < sp.npass; l++)
-    ZK_HIP(hipMemsetAsync(seg_cnt[l], 0, ((size_t)sp.segs[l + 1] + 1) * 4, st));
+  ZK_HIP(hipMemsetAsync(zero_lo, 0, zero_bytes, st));
   const uint32_t nblk = (p.n + 255) / 256;
   if (p.n) hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
   for (uint32_t l = 0; l < sp.npass; l++) {
@@ -995,12 +1030,14 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
       if (last) {
         scan_u32(st, sr.counts, p.TB, 0, 0, sr.off0, block_sums, misc + 0, misc + 1);
         scan_u32(st, sr.counts, p.TB, 1, p.K0, sr.po_a, block_sums, misc + 2, nullptr);
+        hipLaunchKernelGGL(msm_piece_hist_kernel, dim3((p.TB + 255) / 256), dim3(256), 0, st, (const uint32_t*)sr.counts,
+                           p.TB, p.K0, len_hist);
       } else {
         scan_u32(st, seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], block_sums, misc + 4 + 2 * l, nullptr);
         scan_u32(st, seg_cnt[l], sp.segs[l + 1], 1, sp.CH, seg_tpo[l], block_sums, misc + 5 + 2 * l, nullptr);
       }
-    } else if (last) {   // bucket counts -> entry offsets + piece offsets (+ the largest bucket), one launch
-      scan_pair(lane, ScanPair{sr.counts, p.TB, 0, 0, sr.off0, misc + 0, 1, p.K0, sr.po_a, misc + 2, misc + 1});
+    } else if (last) {   // bucket counts -> entry offsets + piece offsets (+ the largest bucket, the piece lengths), one launch
+      scan_pair(lane, ScanPair{sr.counts, p.TB, 0, 0, sr.off0, misc + 0, 1, p.K0, sr.po_a, misc + 2, misc + 1, len_hist, p.K0});
     } else {             // segment counts -> entry offsets + task offsets
       scan_pair(lane, ScanPair{seg_cnt[l], sp.segs[l + 1], 0, 0, seg_off[l], misc + 4 + 2 * l, 1, sp.CH, seg_tpo[l],
                                misc + 5 + 2 * l, nullptr});
@@ -1021,11 +1058,10 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   sr.max_count = hb[1];
   sr.total1 = hb[2];
   if (sr.total1) {
-    const uint32_t pgrid = (sr.total1 + 255) / 256;
-    hipLaunchKernelGGL(msm_piece_len_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)sr.counts,
-                       (const uint32_t*)sr.po_a, p.TB, p.K0, sr.pbkt, plen, len_hist);
-    hipLaunchKernelGGL(msm_piece_order_kernel, dim3(pgrid), dim3(256), 0, st, (const uint32_t*)plen,
-                       (const uint32_t*)sr.po_a, p.TB, (const uint32_t*)len_hist, len_cursor, sr.order);
+    const uint32_t per_block = 256u * kPiecesPerThread;
+    hipLaunchKernelGGL(msm_piece_order_kernel, dim3((sr.total1 + per_block - 1) / per_block), dim3(256), 0, st,
+                       (const uint32_t*)sr.counts, (const uint32_t*)sr.po_a, p.TB, p.K0, (const uint32_t*)len_hist,
+                       len_cursor, sr.pbkt, sr.order);
   }
   if (sync_at_end) ZK_HIP(hipStreamSynchronize(st));  // other lanes are about to read the result
   return sr;
@@ -1065,7 +1101,6 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
   char* Y1 = ws.take<char>((size_t)(S1 * sums) * MsmSizes<F>::kXyzz);
   char* Y2 = ws.take<char>((size_t)(S1 * sums) * MsmSizes<F>::kXyzz);
 
-  ZK_HIP(hipMemsetAsync(buckets, 0, (size_t)p.TB * MsmSizes<F>::kXyzz, st));
   if (accum_ms) ZK_HIP(hipEventRecord(lane.ev0, st));
   if (sr.total1) {
     const uint32_t pgrid = (sr.total1 + 255) / 256;
@@ -1102,8 +1137,8 @@ inline void msm_accum_phase(Lane& lane, const MsmSorted& sr, const void* d_bases
     uint32_t log_parts = msm_reduce_log_parts(p.logRows, p.logS, p.Wb);
     uint64_t threads = ((uint64_t)p.Wb << log_parts) * ((1u << p.logRows) + E);
     hipLaunchKernelGGL((msm_bucket_sums_kernel<F>), dim3((uint32_t)((threads + 255) / 256)), dim3(256),
-                       256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, p.Wb, p.Nb, p.logS, p.logRows, log_parts, E,
-                       (void*)X);
+                       256 * MsmSizes<F>::kXyzz, st, (const void*)buckets, (const uint32_t*)sr.counts, p.Wb, p.Nb, p.logS,
+                       p.logRows, log_parts, E, (void*)X);
   }
   char* ybuf[2] = {Y1, Y2};
   int yi = 0;

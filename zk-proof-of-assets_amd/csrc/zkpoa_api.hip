@@ -24,6 +24,7 @@ extern "C" int zkpoa_context_create(int device, zkpoa_context** out, char* error
   try {
     // the uploader's pinned staging buffers (24 MiB, ~15 ms to pin) come up with the copy stream, off the main thread
     c->dev.after_copy_stream = [c, device](hipStream_t st) { c->uploader.prepare(device, st); };
+    c->dev.after_lanes = [c, device] { c->uploader.add_streams(device); };
     c->dev.init(device);
     for (int i = 0; i < DeviceCtx::kLanes; i++) {
       ZK_HIP(hipEventCreate(&c->ev_a[i]));
@@ -49,6 +50,10 @@ extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
   }
   ntt_release(ctx);
   poseidon_release(ctx);
+  try {
+    ctx->dev.wait_lanes();   // the background thread may still be adding the uploader's streams
+  } catch (...) {
+  }
   ctx->uploader.release();
   ctx->dev.destroy();
   delete ctx;
