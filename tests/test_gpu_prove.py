@@ -470,6 +470,50 @@ def test_prover_cli_server_mode(zk, tmp_path):
     assert not os.path.exists(sock)
 
 
+def test_server_overlaps_requests_without_mixing_them_up(zk, tmp_path):
+    """The resident prover serves requests from a pool of threads: the witness of one request is staged into the key's
+    second buffer while another request proves (two locks inside zkpoa_groth16_prover_files), and r, s and the JSON style
+    travel per request and per thread, never through the server's environment. Twelve clients at once -- two witnesses,
+    six (r, s) pairs, both JSON styles -- must each get exactly the proof the Python oracle computes for ITS inputs."""
+    g = golden_case("n128")
+    zkey = g["circuit.zkey"]
+    _, w0 = g16.read_wtns(g["witness.wtns"])
+    # (two witness FILES with the same values: what differs per request is the file, r, s and the JSON style)
+    (tmp_path / "circuit_final.zkey").write_bytes(zkey)
+    (tmp_path / "wa.wtns").write_bytes(g["witness.wtns"])
+    (tmp_path / "wb.wtns").write_bytes(g16.write_wtns(w0))
+    sock = str(tmp_path / "prover.sock")
+    env = dict(os.environ, ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60", ZKPOA_SERVER_WORKERS="3")
+    for k in ("ZKPOA_R", "ZKPOA_S", "ZKPOA_JSON", "ZKPOA_VERBOSE"):
+        env.pop(k, None)
+    rng = random.Random(4242)
+    try:
+        # two sequential calls first: load, then the table build of the second use -- the steady state follows
+        for i in range(2):
+            rc = subprocess.run([zk.PROVER_BIN, "circuit_final.zkey", "wa.wtns", "warm.json", "warm_pub.json"],
+                                env=dict(env, ZKPOA_R="1", ZKPOA_S="2"), capture_output=True, text=True, cwd=tmp_path, timeout=120)
+            assert rc.returncode == 0, rc.stderr
+        jobs = []
+        for i in range(12):
+            r_, s_ = rng.randrange(bn.R), rng.randrange(bn.R)
+            style = "snarkjs" if i % 3 == 0 else "rapidsnark"
+            wt = "wa.wtns" if i % 2 == 0 else "wb.wtns"
+            e = dict(env, ZKPOA_R=str(r_), ZKPOA_S=str(s_))
+            if style == "snarkjs":
+                e["ZKPOA_JSON"] = "snarkjs"
+            pr = subprocess.Popen([zk.PROVER_BIN, "circuit_final.zkey", wt, "p%d.json" % i, "u%d.json" % i], env=e,
+                                  cwd=tmp_path, stderr=subprocess.PIPE, text=True)
+            jobs.append((i, r_, s_, style, pr))
+        for i, r_, s_, style, pr in jobs:
+            _, err = pr.communicate(timeout=180)
+            assert pr.returncode == 0, err
+            proof, public = g16.prove(zkey, g["witness.wtns"], r_, s_)
+            want = g16.proof_json_snarkjs(proof) if style == "snarkjs" else g16.proof_json_rapidsnark(proof)
+            assert (tmp_path / ("p%d.json" % i)).read_text() == want, "request %d got somebody else's proof" % i
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
 def test_prover_cli_failure_leaves_no_output(zk, tmp_path):
     g = golden_case("n8")
     _, w = g16.read_wtns(g["witness.wtns"])

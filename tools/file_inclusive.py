@@ -120,6 +120,29 @@ def one_shape(z, spec, args):
                 sruns.append(run_cli(z, paths, senv, "via the resident server, call %d (%s)" % (i, tag)))
                 assert sruns[-1]["rc"] == 0, sruns[-1]
                 assert open(paths[2]).read() == want_json, "server proof differs from the HBM-resident proof"
+            # two clients at a time, as the reference's parallel batch jobs (scripts/full_workflow.sh:552): the server stages
+            # one request's witness while it proves the other's -- the period per proof is what a workflow sees
+            import threading
+            per_client = 4
+
+            def client(idx, out):
+                p2 = [zp, wp, os.path.join(d, "proof_c%d.json" % idx), os.path.join(d, "public_c%d.json" % idx)]
+                for _ in range(per_client):
+                    r = subprocess.run([z.PROVER_BIN] + p2, env=dict(senv, ZKPOA_VERBOSE=""), capture_output=True, text=True)
+                    out.append(r.returncode)
+                assert open(p2[2]).read() == want_json
+            for nclients in (1, 2, 3):
+                outs = [[] for _ in range(nclients)]
+                th = [threading.Thread(target=client, args=(i, outs[i])) for i in range(nclients)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = time.perf_counter() - t0
+                assert all(rc == 0 for o in outs for rc in o), outs
+                rec.setdefault("server_concurrent", {})[str(nclients)] = {
+                    "clients": nclients, "proofs": nclients * per_client, "ms_per_proof": dt / (nclients * per_client) * 1e3}
         finally:
             subprocess.run([z.PROVER_BIN, "--stop-server"], env=senv)
             settle(rec["table_gb"] * 1.5 + zkey_bytes / 1e9 + 40)
@@ -156,6 +179,7 @@ def main():
         brief = {kk: v for kk, v in rec.items() if kk in ("hbm_resident_ms", "server_steady_ms", "server_steady_over_resident", "skipped")}
         brief["one_shot_s"] = [round(r["wall_s"], 3) for r in rec.get("one_shot", [])]
         brief["server_s"] = [round(r["wall_s"], 3) for r in rec.get("server", [])]
+        brief["server_concurrent_ms_per_proof"] = {k: round(v["ms_per_proof"], 1) for k, v in rec.get("server_concurrent", {}).items()}
         print(json.dumps(brief), flush=True)
 
 

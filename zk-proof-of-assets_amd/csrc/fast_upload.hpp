@@ -6,6 +6,9 @@
 #pragma once
 #include "device_ctx.hpp"
 
+#include <ctype.h>
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -54,6 +57,7 @@ class FastUploader {
       th.emplace_back([this, t, lo, hi, dst, src, device, stream, fd, file_off, &errs] {
         try {
           ZK_HIP(hipSetDevice(device));
+          if (have_cpus_) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpus_), &cpus_);
           Slot& s = slots_[t];
           // streams: the caller's plus the uploader's own, as many as exist by now (they come up in the background);
           // one stream -- one SDMA queue -- moves ~36 GB/s whatever the thread count, four reach the link's ~53 GB/s
@@ -129,6 +133,8 @@ class FastUploader {
   void* block_ = nullptr;
   bool ready_ = false;
   int threads_ = 8;
+  cpu_set_t cpus_;            // ZKPOA_UPLOAD_AFFINITY=gpu: the CPUs of the GPU's NUMA node (staging copies stay on its socket)
+  bool have_cpus_ = false;
   static constexpr int kMaxOwnStreams = 8;
   hipStream_t own_[kMaxOwnStreams] = {};
   std::atomic<int> n_own_{0};
@@ -140,6 +146,48 @@ class FastUploader {
       if (r <= 0) throw HipError("upload: short read from the file");
       got += (size_t)r;
     }
+  }
+
+  // CPUs of the NUMA node the GPU hangs off (sysfs: the PCI device's numa_node, that node's cpulist); false when unknown
+  static bool gpu_node_cpus(int device, cpu_set_t* out) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return false;
+    for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    int node = -1;
+    if (!f || fscanf(f, "%d", &node) != 1) node = -1;
+    if (f) fclose(f);
+    if (node < 0) return false;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    CPU_ZERO(out);
+    int a = 0, b = 0, n = 0;
+    char sep = 0;
+    while (fscanf(f, "%d", &a) == 1) {
+      b = a;
+      int ch = fgetc(f);
+      if (ch == '-') {
+        if (fscanf(f, "%d", &b) != 1) break;
+        ch = fgetc(f);
+      }
+      for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
+        CPU_SET(c, out);
+        n++;
+      }
+      sep = (char)ch;
+      if (sep != ',') break;
+    }
+    fclose(f);
+    // only CPUs this process may use at all
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+      CPU_AND(out, out, &allowed);
+      n = CPU_COUNT(out);
+    }
+    return n > 0;
   }
 
   std::mutex ensure_mutex_;
@@ -158,7 +206,16 @@ class FastUploader {
     unsigned hw = std::thread::hardware_concurrency();
     if (hw && (int)hw < threads_) threads_ = (int)hw;
     ZK_HIP(hipSetDevice(device));
+    if (const char* e = getenv("ZKPOA_UPLOAD_AFFINITY"))
+      if (!strcmp(e, "gpu")) have_cpus_ = gpu_node_cpus(device, &cpus_);
+    cpu_set_t before;
+    const bool moved = have_cpus_ && pthread_getaffinity_np(pthread_self(), sizeof(before), &before) == 0 &&
+                       pthread_setaffinity_np(pthread_self(), sizeof(cpus_), &cpus_) == 0;
     ZK_HIP(hipHostMalloc(&block_, (size_t)threads_ * 2 * kChunk, hipHostMallocDefault));   // one pinning call
+    if (moved) {
+      memset(block_, 0, (size_t)threads_ * 2 * kChunk);   // first touch on the GPU's node
+      (void)pthread_setaffinity_np(pthread_self(), sizeof(before), &before);
+    }
     for (int t = 0; t < threads_; t++) {
       Slot& s = slots_[t];
       for (int b = 0; b < 2; b++) {

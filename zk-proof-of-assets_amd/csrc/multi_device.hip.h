@@ -240,7 +240,7 @@ DeviceSet* process_devices(uint32_t power, std::string& err, int* code) {
           ds->peer_ok = false;   // no direct path between this pair: the exchanges go through hipMemcpyPeerAsync
         }
       }
-    if (getenv("ZKPOA_VERBOSE")) {
+    if (req_getenv("ZKPOA_VERBOSE")) {
       std::string list;
       for (size_t g = 0; g < G; g++) list += (g ? "," : "") + std::to_string(ds->ids[g]);
       fprintf(stderr, "zkpoa: %zu rank(s) on HIP device(s) %s%s, contexts ready in %.1f ms\n", G, list.c_str(),
@@ -575,7 +575,7 @@ int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const WtnsSrc& wsrc, char* 
   std::vector<uint8_t> pub_store;
   const uint8_t* pubs = w.publics(z0->nPublic, pub_store);
   selfcheck(c0, z0, pts, pubs);
-  if (getenv("ZKPOA_VERBOSE"))
+  if (req_getenv("ZKPOA_VERBOSE"))
     fprintf(stderr, "zkpoa: one proof over %zu ranks: H-scalar chain %s, sections 5-8 %s, %.2f GB of fixed-base tables; "
                     "prove %.2f ms\n", ds->ids.size(), mk->split ? "split (2 peer-to-peer exchanges)" : "replicated",
             z0->bc_log ? "block-cyclic" : "contiguous ranges", mk->table_bytes / 1e9, c0->ms[5]);

@@ -39,6 +39,29 @@ struct ProverError : std::runtime_error {
   ProverError(int c, const std::string& s) : std::runtime_error(s), code(c) {}
 };
 
+// ---- per-request options ---------------------------------------------------------------------------------
+// The one-shot entry points take r, s, the JSON style and verbosity from the environment (ZKPOA_R / _S / _JSON /
+// _VERBOSE). A resident server answers several clients from several threads and must not mutate its process
+// environment per request: zkpoa_set_thread_options gives the calling thread values that take precedence over the
+// environment for its following calls (empty string = "unset for this thread even if the environment has it").
+struct ReqOptions {
+  bool active = false;
+  std::string r, s, json, verbose;
+};
+ReqOptions& req_options() {
+  static thread_local ReqOptions o;
+  return o;
+}
+const char* req_getenv(const char* name) {
+  const ReqOptions& o = req_options();
+  if (o.active) {
+    const std::string* v = !strcmp(name, "ZKPOA_R") ? &o.r : !strcmp(name, "ZKPOA_S") ? &o.s :
+                           !strcmp(name, "ZKPOA_JSON") ? &o.json : !strcmp(name, "ZKPOA_VERBOSE") ? &o.verbose : nullptr;
+    if (v) return v->empty() ? nullptr : v->c_str();
+  }
+  return getenv(name);
+}
+
 // ---- binfile container: magic[4] u32 version u32 nSections {u32 id u64 len payload}*
 struct Section {
   const uint8_t* p = nullptr;
@@ -94,7 +117,7 @@ void* dev_upload(zkpoa_context* ctx, const void* src, size_t bytes) {
   auto t1 = std::chrono::steady_clock::now();
   try {
     if (bytes) ctx->uploader.upload(d, src, bytes, ctx->dev.device, ctx->dev.lanes[0].stream);
-    if (getenv("ZKPOA_VERBOSE") && bytes > (16u << 20))
+    if (req_getenv("ZKPOA_VERBOSE") && bytes > (16u << 20))
       fprintf(stderr, "zkpoa:   upload %.0f MB: hipMalloc %.1f ms, copy %.1f ms\n", bytes / 1e6,
               std::chrono::duration<double, std::milli>(t1 - t0).count(),
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -126,7 +149,12 @@ struct zkpoa_zkey {
   void* d_vals = nullptr;
   uint32_t* d_flag = nullptr; // [0]: a witness value >= r was seen by the last prove (range_check_kernel)
   void* d_abc = nullptr;      // 3 * domain * 32 B work area (A_T, B_T, C_T)
-  void* d_witness = nullptr;  // nVars * 32 B
+  mutable void* d_witness = nullptr;  // nVars * 32 B: the witness the next prove reads
+  // Witness staging of the resident prover (zkey_file_prove): two buffers, so that the witness of the NEXT request is
+  // uploaded while the current proof computes; d_witness points at the one being proved. wbuf[0] adopts the buffer the
+  // key was loaded with, wbuf[1] is allocated when a second request first overlaps.
+  mutable void* wbuf[2] = {nullptr, nullptr};
+  mutable bool wbusy[2] = {false, false};
   bool owns_points = true;    // false when the point sections belong to the caller (zkpoa_zkey_load_device)
   // Shard of the MSMs this handle covers: contiguous global index ranges. The device
   // buffers dA/dB1/dB2 start at global wire index `wbase`, dC at C-section index `cbase`, dH at `hbase`.
@@ -184,7 +212,7 @@ struct zkpoa_zkey {
   // and sizes the windows of later proofs and of the witness tables (zkey_precompute after a proof).
   mutable double witness_density[32];
   mutable bool have_density = false;
-  uint64_t proofs_done = 0;   // groth16_prover_zkey_file's cache precomputes when a key is used a second time
+  std::atomic<uint64_t> proofs_done{0};   // groth16_prover_zkey_file's cache precomputes when a key is used a second time
   void release_tables() {
     for (MsmTable** t : {&tA, &tB1, &tB2, &tC, &tH}) {
       msm_table_release(*t);
@@ -212,6 +240,13 @@ struct zkpoa_zkey {
     if (owns_points)
       for (void* p : pts)
         if (p) (void)hipFree(p);
+    if (wbuf[0] || wbuf[1]) {   // the staging pair owns the witness memory (d_witness points at one of them)
+      for (void*& w : wbuf) {
+        if (w) (void)hipFree(w);
+        w = nullptr;
+      }
+      d_witness = nullptr;
+    }
     void* ptrs[] = {d_row_ptr, d_sig, d_vals, d_abc, d_witness, dHs, d_long, d_flag, d_cscal};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -474,7 +509,7 @@ zkpoa_zkey* zkey_load_impl(zkpoa_context* ctx, const uint8_t* buf, uint64_t size
     set_split(zk.get(), rank, world);
   }
   set_block_cyclic(zk.get(), rank, world, bc_log);
-  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  const bool verbose = req_getenv("ZKPOA_VERBOSE") != nullptr;
   auto tph = std::chrono::steady_clock::now();
   auto phase = [&](const char* what) {   // ZKPOA_VERBOSE: where a key load spends its time
     if (!verbose) return;
@@ -1148,7 +1183,7 @@ void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_poi
   ctx->ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (rc == PROVER_OK) {
     zk->selfchecks_done++;
-    if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: self-check: proof verifies against the zkey's own verification key (%.1f ms)\n", ctx->ms[6]);
+    if (req_getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa: self-check: proof verifies against the zkey's own verification key (%.1f ms)\n", ctx->ms[6]);
     return;
   }
   if (rc == ZKPOA_VERIFY_INVALID_PROOF)
@@ -1215,7 +1250,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
   std::atomic<bool> cancel{false};
   std::thread uploader;
   Staging stg;
-  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  const bool verbose = req_getenv("ZKPOA_VERBOSE") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto mark = [&, verbose](const char* what) {   // ZKPOA_VERBOSE: the timeline of an overlapped load + prove
     if (verbose)
@@ -1431,6 +1466,37 @@ int emit(const std::string& s, char* buffer, unsigned long* size) {
 std::mutex g_ctx_mutex;
 zkpoa_context* g_ctx = nullptr;
 std::mutex g_prove_mutex;   // one-shot entry points share the process-wide context: one proof at a time
+// The file entry point is entered by several threads of a resident server. Two stages, two locks: g_stage_mutex covers
+// the key cache and the upload of a request's witness into a free staging buffer of its key; g_prove_mutex the proof
+// itself. A request whose key is resident and already has its tables stages its witness while the request before it
+// is still proving -- at the layer-three size that is 31 ms of PCIe time per proof taken off the proof-to-proof period.
+// Anything that changes the cache or a key (a load, the second-use table build, an eviction) waits until no staged
+// request is pending and then holds both locks.
+std::mutex g_stage_mutex;
+std::condition_variable g_stage_cv;
+int g_staged_users = 0;
+
+// the code of a failure for the two file entry points + its message; call inside a catch (...) block
+int classify_current_exception(char* error_msg, unsigned long error_msg_maxsize) {
+  try {
+    throw;
+  } catch (const ProverError& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return e.code;
+  } catch (const HipError& e) {            // HIP runtime failure: the context and its cached keys are suspect
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR_RUNTIME;
+  } catch (const std::bad_alloc&) {
+    set_err(error_msg, error_msg_maxsize, "out of host memory");
+    return PROVER_ERROR_RUNTIME;
+  } catch (const std::system_error& e) {   // a stage thread could not be started
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR_RUNTIME;
+  } catch (const std::exception& e) {
+    set_err(error_msg, error_msg_maxsize, e.what());
+    return PROVER_ERROR;
+  }
+}
 
 struct DeviceSet;
 DeviceSet* process_devices(uint32_t power, std::string& err, int* code);   // multi_device.hip.h: the device list of this process
@@ -1438,7 +1504,7 @@ DeviceSet* process_devices(uint32_t power, std::string& err, int* code);   // mu
 // r, s from the environment (ZKPOA_R / ZKPOA_S, decimal; test use) -> pointers, or null for /dev/urandom
 void env_blinding(uint8_t rb[32], uint8_t sb[32], const uint8_t*& rp, const uint8_t*& sp) {
   rp = sp = nullptr;
-  if (getenv("ZKPOA_R") || getenv("ZKPOA_S")) {
+  if (req_getenv("ZKPOA_R") || req_getenv("ZKPOA_S")) {
     static bool warned = false;
     if (!warned) {
       warned = true;
@@ -1446,11 +1512,11 @@ void env_blinding(uint8_t rb[32], uint8_t sb[32], const uint8_t*& rp, const uint
                       "not zero-knowledge; unset them in production\n");
     }
   }
-  if (const char* e = getenv("ZKPOA_R")) {
+  if (const char* e = req_getenv("ZKPOA_R")) {
     if (!parse_decimal_mod_r(e, rb)) throw ProverError(PROVER_ERROR, "ZKPOA_R is not a decimal number");
     rp = rb;
   }
-  if (const char* e = getenv("ZKPOA_S")) {
+  if (const char* e = req_getenv("ZKPOA_S")) {
     if (!parse_decimal_mod_r(e, sb)) throw ProverError(PROVER_ERROR, "ZKPOA_S is not a decimal number");
     sp = sb;
   }
@@ -1462,7 +1528,7 @@ int emit_outputs(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t pts[256
                  unsigned long error_msg_maxsize, double load_ms, uint64_t zkey_size, const char* how) {
   int rc = PROVER_OK;
   int style = 0;
-  if (const char* e = getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
+  if (const char* e = req_getenv("ZKPOA_JSON")) style = (strcmp(e, "snarkjs") == 0) ? 1 : 0;
   std::string pj = proof_json(pts, style), uj = public_json(pub, zk->nPublic, style);
   int r1 = emit(pj, proof_buffer, proof_size);
   int r2 = emit(uj, public_buffer, public_size);
@@ -1470,7 +1536,7 @@ int emit_outputs(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t pts[256
     rc = PROVER_ERROR_SHORT_BUFFER;
     set_err(error_msg, error_msg_maxsize, "output buffer too small");
   }
-  if (getenv("ZKPOA_VERBOSE")) {
+  if (req_getenv("ZKPOA_VERBOSE")) {
     fprintf(stderr,
             "zkpoa: nVars=%u nPublic=%u domain=2^%u nCoefs=%llu | zkey %s %.1f ms (%.2f GB/s) | witness -> HBM %.2f ms "
             "(%.0f MB, %.1f GB/s) | h-chain %.2f ms, msm phase %.2f ms, prove %.2f ms, self-check %.2f ms\n",
@@ -1697,7 +1763,7 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
       if (!e || strcmp(e, "0") != 0) {
         auto tp0 = std::chrono::steady_clock::now();
         multi_precompute(ds, mk);
-        if (getenv("ZKPOA_VERBOSE"))
+        if (req_getenv("ZKPOA_VERBOSE"))
           fprintf(stderr, "zkpoa: fixed-base tables for the cached key on %zu ranks: %.2f GB in %.0f ms\n", ds->ids.size(),
                   mk->table_bytes / 1e9,
                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
@@ -1730,6 +1796,58 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
     rc = PROVER_ERROR;
   }
   if (mk && !cached) multi_key_release(ds, mk);
+  return rc;
+}
+
+// A request on a resident key in steady state (cached, tables built or not wanted): the witness goes into a free
+// staging buffer under the stage lock -- which is then dropped -- and the proof runs under the prove lock. Enters with
+// stage_lk held, leaves with it released.
+int staged_prove(zkpoa_context* ctx, const zkpoa_zkey* zk, const WtnsSrc& wsrc, uint64_t zkey_size,
+                 std::unique_lock<std::mutex>& stage_lk, hipStream_t cs, char* proof_buffer, unsigned long* proof_size,
+                 char* public_buffer, unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize) {
+  int rc = PROVER_OK, slot = -1;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    WtnsView w = parse_wtns(wsrc);
+    if (w.n != zk->nVars)
+      throw ProverError(PROVER_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) +
+                                                           ", witness: " + std::to_string(w.n));
+    if (!zk->wbuf[0]) zk->wbuf[0] = zk->d_witness;   // adopt the buffer the key came with
+    g_stage_cv.wait(stage_lk, [&] { return !zk->wbusy[0] || !zk->wbusy[1]; });
+    slot = !zk->wbusy[0] ? 0 : 1;
+    if (!zk->wbuf[slot]) ZK_HIP(hipMalloc(&zk->wbuf[slot], (size_t)zk->nVars * 32));
+    zk->wbusy[slot] = true;
+    g_staged_users++;
+    const auto tu = std::chrono::steady_clock::now();
+    w.upload(ctx, zk->wbuf[slot], 0, w.n, cs);      // on the copy stream(s): lane 0 may be busy with another proof's chain
+    const float up_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tu).count();
+    std::vector<uint8_t> pub_store;
+    const uint8_t* pubs = w.publics(zk->nPublic, pub_store);
+    stage_lk.unlock();
+    {
+      std::lock_guard<std::mutex> lk(g_prove_mutex);
+      zk->d_witness = zk->wbuf[slot];
+      uint8_t rb[32], sb[32], pts[256];
+      const uint8_t *rp = nullptr, *sp = nullptr;
+      env_blinding(rb, sb, rp, sp);
+      prove_core(ctx, zk, rp, sp, pts);
+      selfcheck(ctx, zk, pts, pubs);
+      ctx->io_ms[0] = up_ms;
+      ctx->io_ms[1] = (float)((double)w.n * 32 / 1e6);
+      rc = emit_outputs(ctx, zk, pts, pubs, proof_buffer, proof_size, public_buffer, public_size, error_msg,
+                        error_msg_maxsize, 0.0, zkey_size, "cached,");
+      const_cast<zkpoa_zkey*>(zk)->proofs_done++;
+    }
+  } catch (...) {
+    rc = classify_current_exception(error_msg, error_msg_maxsize);
+  }
+  if (!stage_lk.owns_lock()) stage_lk.lock();
+  if (slot >= 0) {
+    zk->wbusy[slot] = false;
+    g_staged_users--;
+  }
+  stage_lk.unlock();
+  g_stage_cv.notify_all();
   return rc;
 }
 
@@ -1775,6 +1893,28 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
     return dcode;
   }
   zkpoa_context* ctx = ds->ctx[0];
+  std::unique_lock<std::mutex> stage_lk(g_stage_mutex);
+  auto precomp_wanted = [] {
+    const char* e = getenv("ZKPOA_PRECOMP");
+    return !e || strcmp(e, "0") != 0;
+  };
+  if (ds->ids.size() == 1) {   // steady state of a resident single-GPU key: stage the witness, then prove (two locks)
+    for (auto& c : g_key_cache)
+      if (c.dev == sb.st_dev && c.ino == sb.st_ino && c.size == sb.st_size && c.mtime.tv_sec == sb.st_mtim.tv_sec &&
+          c.mtime.tv_nsec == sb.st_mtim.tv_nsec) {
+        const uint64_t done = c.zk->proofs_done.load();
+        const bool tables_due = done == 1 && c.zk->table_bytes == 0 && precomp_wanted();
+        hipStream_t cs = ctx->dev.copy_stream_wait();
+        if (done >= 1 && !tables_due && cs) {
+          c.last_use = ++g_key_clock;
+          close(fd);
+          return staged_prove(ctx, c.zk, wsrc, (uint64_t)sb.st_size, stage_lk, cs, proof_buffer, proof_size, public_buffer,
+                              public_size, error_msg, error_msg_maxsize);
+        }
+      }
+  }
+  // everything else changes the cache or a key: alone, with both locks
+  g_stage_cv.wait(stage_lk, [] { return g_staged_users == 0; });
   std::lock_guard<std::mutex> lk(g_prove_mutex);
   if (ds->ids.size() > 1) {
     int rc = multi_file_prove(ds, fd, sb, path, wsrc, proof_buffer, proof_size, public_buffer, public_size,
@@ -1796,6 +1936,7 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
         c.last_use = ++g_key_clock;
         hit = true;
       }
+    if (zk && zk->wbuf[0]) zk->d_witness = zk->wbuf[0];   // nothing is staged now: back to the first buffer
     if (!zk) {
       void* map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
       if (map == MAP_FAILED) throw ProverError(PROVER_ERROR, std::string("cannot mmap zkey file ") + path);
@@ -1838,12 +1979,11 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
     }
     // a key that comes out of the cache is being reused: build its fixed-base tables now, once (ZKPOA_PRECOMP=0 off)
     if (hit && !owned && zk->proofs_done == 1 && zk->table_bytes == 0) {
-      const char* e = getenv("ZKPOA_PRECOMP");
-      if (!e || strcmp(e, "0") != 0) {
+      if (precomp_wanted()) {
         auto tp0 = std::chrono::steady_clock::now();
         try {
           uint64_t used = zkey_precompute(ctx, zk, 0);
-          if (getenv("ZKPOA_VERBOSE"))
+          if (req_getenv("ZKPOA_VERBOSE"))
             fprintf(stderr, "zkpoa: fixed-base tables for the cached key: %.2f GB in %.0f ms\n", used / 1e9,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
         } catch (const HipError&) {   // out of HBM: the classic form keeps working
@@ -1856,21 +1996,8 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
       rc = prove_to_json(ctx, zk, wsrc, proof_buffer, proof_size, public_buffer, public_size, error_msg,
                          error_msg_maxsize, load_ms, (uint64_t)sb.st_size, hit);
     zk->proofs_done++;
-  } catch (const ProverError& e) {
-    set_err(error_msg, error_msg_maxsize, e.what());
-    rc = e.code;
-  } catch (const HipError& e) {            // HIP runtime failure: the context and its cached keys are suspect
-    set_err(error_msg, error_msg_maxsize, e.what());
-    rc = PROVER_ERROR_RUNTIME;
-  } catch (const std::bad_alloc&) {
-    set_err(error_msg, error_msg_maxsize, "out of host memory");
-    rc = PROVER_ERROR_RUNTIME;
-  } catch (const std::system_error& e) {
-    set_err(error_msg, error_msg_maxsize, e.what());
-    rc = PROVER_ERROR_RUNTIME;
-  } catch (const std::exception& e) {
-    set_err(error_msg, error_msg_maxsize, e.what());
-    rc = PROVER_ERROR;
+  } catch (...) {
+    rc = classify_current_exception(error_msg, error_msg_maxsize);
   }
   close(fd);
   if (owned && zk) {
@@ -2453,4 +2580,19 @@ extern "C" int zkpoa_groth16_prover_files(const char* zkey_file_path, const char
                            public_buffer, public_size, error_msg, error_msg_maxsize);
   close(wfd);
   return rc;
+}
+
+extern "C" int zkpoa_set_thread_options(const char* r_dec, const char* s_dec, const char* json_style, int verbose) {
+  ReqOptions& o = req_options();
+  o.active = true;
+  o.r = r_dec ? r_dec : "";
+  o.s = s_dec ? s_dec : "";
+  o.json = json_style ? json_style : "";
+  o.verbose = verbose ? "1" : "";
+  return PROVER_OK;
+}
+
+extern "C" int zkpoa_clear_thread_options(void) {
+  req_options() = ReqOptions();
+  return PROVER_OK;
 }

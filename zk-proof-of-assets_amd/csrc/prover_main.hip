@@ -32,15 +32,23 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // The library is loaded on demand (dlopen): a client of the resident server never proves itself, and resolving
 // libzkpoa_prover.so with the HIP runtime behind it costs ~11 ms of every call (measured r04: 28 ms per layer-one
 // proof through the server, of which 15 in the server). Looked for next to this executable, then on the usual path.
 typedef int (*prover_files_fn)(const char*, const char*, char*, unsigned long*, char*, unsigned long*, char*, unsigned long);
+typedef int (*thread_options_fn)(const char*, const char*, const char*, int);
+static thread_options_fn g_set_thread_options = nullptr;   // per-request r, s, JSON style, verbosity of a server thread
+static std::mutex g_load_mutex;
 static prover_files_fn load_prover(std::string& message) {
   static prover_files_fn fn = nullptr;
+  std::lock_guard<std::mutex> lk(g_load_mutex);
   if (fn) return fn;
   std::string tried;
   char exe[PATH_MAX];
@@ -61,6 +69,7 @@ static prover_files_fn load_prover(std::string& message) {
   }
   fn = reinterpret_cast<prover_files_fn>(dlsym(h, "zkpoa_groth16_prover_files"));
   if (!fn) message = "Error: libzkpoa_prover.so does not export zkpoa_groth16_prover_files";
+  g_set_thread_options = reinterpret_cast<thread_options_fn>(dlsym(h, "zkpoa_set_thread_options"));
   return fn;
 }
 
@@ -254,16 +263,24 @@ static int connect_to(const std::string& sock) {
   return fd;
 }
 
-static void set_or_clear(const char* name, const std::string& v) {
-  if (v.empty()) unsetenv(name);
-  else setenv(name, v.c_str(), 1);
-}
-
 // The resident prover: serves requests one at a time (the GPU is the shared resource) until idle or told to stop.
 static int server_main(const std::string& sock) {
   std::string lockp = sock + ".lock";
   int lock = open(lockp.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-  if (lock < 0 || flock(lock, LOCK_EX | LOCK_NB) != 0) return 0;   // another server owns this socket
+  if (lock < 0) return 0;
+  {   // Another server owns this socket -- unless it is on its way out (it removes its socket first, see `leave` below,
+      // and drops the lock a moment later): with no socket in place, wait for the lock a little instead of giving up.
+    bool mine = false;
+    for (int i = 0; i < 150 && !mine; i++) {
+      mine = flock(lock, LOCK_EX | LOCK_NB) == 0;
+      if (!mine) {
+        struct stat sb;
+        if (stat(sock.c_str(), &sb) == 0) return 0;   // a live server is listening
+        usleep(20000);
+      }
+    }
+    if (!mine) return 0;
+  }
   // (the lock file carries no pid: a client identifies the server by the kernel's SO_PEERCRED of its own connection)
   unlink(sock.c_str());                                           // stale socket of a dead server
   int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
@@ -277,19 +294,25 @@ static int server_main(const std::string& sock) {
   if (!ok) return 1;
   int idle_s = 600;
   if (const char* e = getenv("ZKPOA_SERVER_IDLE_S")) idle_s = atoi(e) > 0 ? atoi(e) : idle_s;
-  bool running = true;
-  int exit_code = 0;
-  while (running) {
-    struct pollfd pfd = {ls, POLLIN, 0};
-    int pr = poll(&pfd, 1, idle_s * 1000);
-    if (pr == 0) break;          // idle: give the HBM back
-    if (pr < 0) {
-      if (errno == EINTR) continue;
-      break;
-    }
-    int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
-    if (c < 0) continue;
-    {   // a client that connects and then says nothing must not hold the (single-threaded) server
+  // Requests are served by a small pool of threads (ZKPOA_SERVER_WORKERS, default 2): the library stages the witness
+  // of one request while it proves another (two locks inside zkpoa_groth16_prover_files), so the batch jobs the
+  // reference runs in parallel (scripts/full_workflow.sh:552) do not pay the witness upload one after the other.
+  int workers = 2;
+  if (const char* e = getenv("ZKPOA_SERVER_WORKERS")) workers = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : workers;
+  static const bool test_crash = getenv("ZKPOA_SERVER_TEST_CRASH") != nullptr;   // tests: die with a request in hand
+  std::mutex qm;
+  std::condition_variable qcv;
+  std::vector<int> queue;          // accepted connections waiting for a worker
+  int busy = 0;
+  std::atomic<bool> running{true};
+  std::atomic<int> exit_code{0};
+  int wake[2] = {-1, -1};          // a worker that decides to leave wakes the accept loop at once
+  if (pipe2(wake, O_CLOEXEC | O_NONBLOCK) != 0) wake[0] = wake[1] = -1;
+  // leaving: the socket disappears BEFORE the answer goes out, so that the caller's next request finds no socket and
+  // starts a fresh server instead of queueing behind one that is gone; the main loop is told after the answer is out
+  auto leave = [&] { unlink(sock.c_str()); };
+  auto serve = [&](int c) {
+    {   // a client that connects and then says nothing must not hold a worker
       struct timeval tv = {10, 0};
       if (const char* e = getenv("ZKPOA_SERVER_RCV_TIMEOUT_S")) tv.tv_sec = atoi(e) > 0 ? atoi(e) : 10;
       (void)setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
@@ -298,9 +321,11 @@ static int server_main(const std::string& sock) {
     struct ucred cred;
     socklen_t cl = sizeof(cred);
     std::string req, reply;
+    bool leaving = false;
+    int leave_code = 0;
     if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cred, &cl) != 0 || cred.uid != getuid()) {
       close(c);
-      continue;
+      return;
     }
     if (recv_msg(c, req)) {
       std::vector<std::string> f;
@@ -313,17 +338,19 @@ static int server_main(const std::string& sock) {
       }
       if (!f.empty() && f[0] == "stop") {
         reply = "0";
-        running = false;
+        leaving = true;
+        leave();
       } else if (f.size() >= 9 && f[0] == "prove") {
-        set_or_clear("ZKPOA_R", f[5]);
-        set_or_clear("ZKPOA_S", f[6]);
-        set_or_clear("ZKPOA_JSON", f[7]);
-        set_or_clear("ZKPOA_VERBOSE", f[8]);   // the library's phase line goes to <socket>.log
         const double t0 = now_ms();
         std::string message;
-        static const bool test_crash = getenv("ZKPOA_SERVER_TEST_CRASH") != nullptr;   // read once, at the first request
-        if (test_crash) _exit(3);                        // tests: the server dies with a request in hand
+        if (test_crash) _exit(3);
         bool runtime_failure = false;
+        // r, s, JSON style and verbosity of THIS request, for this thread only (the library's phase line of a verbose
+        // request goes to <socket>.log); never through the process environment: other workers are proving
+        (void)load_prover(message);
+        if (g_set_thread_options)
+          g_set_thread_options(f[5].empty() ? nullptr : f[5].c_str(), f[6].empty() ? nullptr : f[6].c_str(),
+                               f[7].empty() ? nullptr : f[7].c_str(), f[8].empty() ? 0 : 1);
         int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message, &runtime_failure);
         if (rc == EXIT_SUCCESS && !f[8].empty())
           message = "zkpoa: prover server pid " + std::to_string((long)getpid()) + " served the proof in " +
@@ -333,27 +360,84 @@ static int server_main(const std::string& sock) {
           // This process's HIP context (and every key cached in it) is suspect: hand the request back to the client
           // and leave, so that the next call starts a fresh server instead of failing until the idle timeout.
           reply = "R" + message;
-          running = false;
-          exit_code = 4;
+          leaving = true;
+          leave_code = 4;
+          leave();
         }
       } else {
         reply = "1Error: malformed request to the prover server";
       }
-      if (!running) {   // leaving: the socket disappears BEFORE the answer goes out, so that the caller's next request
-        unlink(sock.c_str());   // finds no socket and starts a fresh server instead of queueing behind one that is gone
-        close(ls);
-        ls = -1;
-      }
       send_msg(c, reply);
     }
     close(c);
+    if (leaving) {
+      if (leave_code) exit_code.store(leave_code);
+      running.store(false);
+      if (wake[1] >= 0) (void)!write(wake[1], "x", 1);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int w = 0; w < workers; w++)
+    pool.emplace_back([&] {
+      for (;;) {
+        int c = -1;
+        {
+          std::unique_lock<std::mutex> lk(qm);
+          qcv.wait(lk, [&] { return !queue.empty() || !running.load(); });
+          if (queue.empty()) return;
+          c = queue.front();
+          queue.erase(queue.begin());
+          busy++;
+        }
+        serve(c);
+        {
+          std::lock_guard<std::mutex> lk(qm);
+          busy--;
+        }
+        qcv.notify_all();
+      }
+    });
+  double last_activity = now_ms();
+  while (running.load()) {
+    struct pollfd pfd[2] = {{ls, POLLIN, 0}, {wake[0], POLLIN, 0}};
+    int pr = poll(pfd, wake[0] >= 0 ? 2 : 1, 200);   // (short slices all the same: the idle clock)
+    if (pr < 0 && errno != EINTR) break;
+    if (!running.load()) break;
+    if (pr > 0 && (pfd[0].revents & POLLIN)) {
+      int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+      if (c >= 0) {
+        {
+          std::lock_guard<std::mutex> lk(qm);
+          queue.push_back(c);
+        }
+        qcv.notify_one();
+      }
+      last_activity = now_ms();
+      continue;
+    }
+    bool idle;
+    {
+      std::lock_guard<std::mutex> lk(qm);
+      idle = busy == 0 && queue.empty();
+      if (!idle) last_activity = now_ms();
+    }
+    if (idle && now_ms() - last_activity >= idle_s * 1e3) break;   // idle: give the HBM back
   }
-  if (ls >= 0) {
-    unlink(sock.c_str());
-    close(ls);
+  running.store(false);
+  unlink(sock.c_str());
+  close(ls);
+  qcv.notify_all();
+  if (exit_code.load()) {   // a failed HIP context: no teardown, and nobody waits for workers stuck in it
+    close(lock);
+    _exit(exit_code.load());
   }
+  {   // connections still queued get no answer: their clients prove in-process
+    std::lock_guard<std::mutex> lk(qm);
+    for (int c : queue) close(c);
+    queue.clear();
+  }
+  for (auto& t : pool) t.join();
   close(lock);
-  if (exit_code) _exit(exit_code);   // no HIP teardown on a context that has already failed
   return 0;
 }
 

@@ -2,8 +2,12 @@
 // MSM entry points, host-only group helpers. Kernels live in the per-group translation units.
 #include "zkpoa_internal.hpp"
 
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <chrono>
 
 using namespace zkpoa;
 
@@ -98,6 +102,27 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
   }
   ctx->last_error = std::string("unknown option ") + key;
   return PROVER_ERROR;
+}
+
+// measurement hook (tools/upload_bench.py; not in the public header): `bytes` of the file at `path` from offset `off`
+// into device memory through the context's uploader, exactly as a witness or a zkey section travels. *ms <- host time.
+extern "C" int zkpoa_test_upload(zkpoa_context* ctx, const char* path, uint64_t off, uint64_t bytes, void* d_dst, float* ms) {
+  if (!ctx || !path || !d_dst) return PROVER_ERROR;
+  int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return PROVER_ERROR;
+  int rc = PROVER_OK;
+  try {
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    ctx->dev.wait_lanes();
+    const auto t0 = std::chrono::steady_clock::now();
+    ctx->uploader.upload(d_dst, nullptr, bytes, ctx->dev.device, ctx->dev.lanes[0].stream, fd, off);
+    if (ms) *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  } catch (const std::exception& e) {
+    ctx->last_error = e.what();
+    rc = PROVER_ERROR;
+  }
+  close(fd);
+  return rc;
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------
