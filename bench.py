@@ -33,6 +33,8 @@ VALU_PEAK_GADDS = 13.6      # XYZZ mixed additions/s the integer pipe allows on 
                             # The register-only loop of the same addition reaches 12.6 G/s at 4 waves/SIMD (12.15 at 3) and was
                             # r02's "peak" -- the kernel, whose base loads hide under the arithmetic, runs above it, so it was
                             # not a ceiling
+G2_VALU_PEAK_GADDS = 3.74   # the same bound for the G2 mixed addition: 8 Fq2 products at 45.3 G/s + 2 Fq2 squares (4 Fq
+                            # products at 139.8 G/s) + 14 Fq additions / subtractions (profiles/r03_microbench.txt)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 G1_MSM_BYTES_PER_POINT = 96      # 64 B base + 32 B scalar, each read once
 DTYPE = "u32x8 (254-bit modular integer)"
@@ -510,12 +512,15 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
             try:
                 solo = {"h_chain": 0.0}
                 solo.update({"msm_%s" % x: 0.0 for x in names})
+                accum = {x: [0.0, 0.0] for x in names}    # accumulation kernel alone: ms, millions of mixed additions
                 for _ in range(2):
                     if circ.prove(0, 0)[0] != pts:
                         raise BenchError("serialised prove differs from the overlapped one")
                     solo["h_chain"] += ctx.last_ms(3) / 2
                     for lane, x in enumerate(names):
                         solo["msm_%s" % x] += ctx.last_ms_lane(lane, 0) / 2
+                        accum[x][0] += ctx.last_ms_lane(lane, 1) / 2
+                        accum[x][1] += ctx.last_ms_lane(lane, 2) / 2
             finally:
                 ctx.set_option("prove_serial", 1 if serial else 0)
 
@@ -561,6 +566,17 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
                 "algorithmic_bytes": alg,
                 "phase_ms_overlapped": {kk: v / steps for kk, v in acc.items()}}
         if solo is not None:
+            # the accumulation kernels of the five MSMs against the integer pipe: G1 against the
+            # 13.6 G additions/s its parts allow, the G2 one (B2) against 3.74 G/s (8 Fq2 products at 45.3 G/s + 2 Fq2
+            # squares + 14 Fq additions, tools/microbench.hip) -- it runs at 2 waves per SIMD, where one wave's issue
+            # rate, not the pipe, sets the pace ("why the G2 kernel stays at 0.78")
+            roof["valu_accum"] = {
+                x: {"kernel_ms_solo": accum[x][0], "mixed_additions_M": accum[x][1],
+                    "achieved_Gadds": accum[x][1] / accum[x][0] * 1e-3 if accum[x][0] > 0 else None,
+                    "peak_Gadds": G2_VALU_PEAK_GADDS if x == "B2" else VALU_PEAK_GADDS,
+                    "frac": (accum[x][1] / accum[x][0] * 1e-3 / (G2_VALU_PEAK_GADDS if x == "B2" else VALU_PEAK_GADDS))
+                            if accum[x][0] > 0 else None}
+                for x in names}
             tot = sum(solo.values())
             roof["valu"] = {"stage_ms_solo": solo, "sum_solo_ms": tot, "wall_ms": sec * 1e3, "ratio": tot / (sec * 1e3),
                             "note": "every stage timed alone on the chip (prove_serial) vs the overlapped proof: "

@@ -71,6 +71,16 @@ int zkpoa_groth16_prover_files(const char* zkey_file_path, const char* wtns_file
                                char* public_buffer, unsigned long* public_size,
                                char* error_msg, unsigned long error_msg_maxsize);
 
+/* Per-thread request options for the three entry points above. They read r, s (ZKPOA_R / ZKPOA_S, decimal; test use),
+ * the JSON style (ZKPOA_JSON=snarkjs) and verbosity (ZKPOA_VERBOSE) from the environment; a host that serves several
+ * requests from several threads (the `prover` executable's resident server does) cannot change its environment per
+ * request. After zkpoa_set_thread_options the CALLING THREAD's following calls use these values instead: a NULL string /
+ * verbose 0 means "unset for this thread, whatever the environment says". zkpoa_clear_thread_options returns the thread
+ * to the environment. Calls from different threads may overlap: a request on a resident key stages its witness while
+ * the previous request is still proving. */
+int zkpoa_set_thread_options(const char* r_decimal, const char* s_decimal, const char* json_style, int verbose);
+int zkpoa_clear_thread_options(void);
+
 /* ---- context ----------------------------------------------------------------------------- */
 typedef struct zkpoa_context zkpoa_context;
 typedef struct zkpoa_zkey zkpoa_zkey;
@@ -231,7 +241,8 @@ int zkpoa_msm_g2_device(zkpoa_context* ctx, const void* d_bases, const void* d_s
 int zkpoa_ntt_device(zkpoa_context* ctx, void* d_data, unsigned log_n, int inverse);
 /* G1 MSM on an explicit lane (0..5: an independent HIP stream + workspace each): lets a caller keep
  * several MSMs in flight from several host threads, as zkpoa_prove does internally with its five MSMs.
- * Calls on the same lane must not overlap. zkpoa_last_ms_lane: id 0 = whole MSM, 1 = accumulation kernel. */
+ * Calls on the same lane must not overlap. zkpoa_last_ms_lane: id 0 = whole MSM (ms), 1 = its accumulation kernel (ms),
+ * 2 = that kernel's mixed additions in millions (the non-zero digits of the scalars: the work the VALU roofline counts). */
 int zkpoa_msm_g1_device_lane(zkpoa_context* ctx, int lane, const void* d_bases, const void* d_scalars, uint64_t n,
                              uint8_t out[64]);
 float zkpoa_last_ms_lane(const zkpoa_context* ctx, int lane, int id);

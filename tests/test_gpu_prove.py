@@ -397,6 +397,56 @@ def test_prover_cli_several_ranks_2p16_vs_c_oracle(ctx, zk, tmp_path, witness_li
     assert (tmp_path / "proof_copy.json").read_text() == want
 
 
+def test_prover_cli_over_distinct_gpus(zk, tmp_path):
+    """Only on a node with two or more GPUs (the one-GPU test box skips it): the drop-in with one rank per
+    DISTINCT device -- hipDeviceEnablePeerAccess for every pair, the exchange and witness-slice kernels storing through
+    peer-mapped addresses, consumed after a cross-device hipStreamWaitEvent -- and the same with the exchanges as
+    hipMemcpyPeerAsync copies (ZKPOA_EXCHANGE=copy), and with the devices picked by the per-GPU lock files; every
+    variant must write the golden proof bytes, and the 2^16 key the C oracle's proof."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs")
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    base = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_VERBOSE="1")
+    for k in ("ZKPOA_SERVER", "ZKPOA_DEVICE", "ZKPOA_DEVICES"):
+        base.pop(k, None)
+    world = 8 if ngpu >= 8 else 4 if ngpu >= 4 else 2
+    devs = ",".join(str(d) for d in range(world))
+    argv = [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"]
+    for extra in ({"ZKPOA_DEVICES": devs}, {"ZKPOA_DEVICES": devs, "ZKPOA_EXCHANGE": "copy"},
+                  {"ZKPOA_MULTI_MIN_POWER": "0"}):                     # the last: automatic choice by lock files
+        if os.path.exists(tmp_path / "proof.json"):
+            os.remove(tmp_path / "proof.json")
+        rc = subprocess.run(argv, env=dict(base, **extra), capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert rc.returncode == 0, rc.stderr
+        assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"], extra
+        assert "%d rank(s)" % world in rc.stderr or "ZKPOA_MULTI_MIN_POWER" in extra, rc.stderr
+    # a mid-size key against the C oracle, real block-cyclic shards on the distinct devices
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    ctx = zk.Context(0)
+    try:
+        circ = SyntheticCircuit(zk, ctx, 16, 60000, n_public=2, seed=78, witness_like=True)
+        try:
+            zkey, wtns = circ.zkey_image(), circ.wtns_image()
+        finally:
+            circ.close()
+    finally:
+        ctx.close()
+    (tmp_path / "mid.zkey").write_bytes(zkey)
+    (tmp_path / "mid.wtns").write_bytes(wtns)
+    want_pts, _ = co.prove(zkey, wtns, 11, 22, 8, n_public=2)
+    for extra in ({}, {"ZKPOA_EXCHANGE": "copy"}):
+        rc = subprocess.run([zk.PROVER_BIN, "mid.zkey", "mid.wtns", "mid.json", "mid_pub.json"],
+                            env=dict(base, ZKPOA_R="11", ZKPOA_S="22", ZKPOA_SELFCHECK="0", ZKPOA_DEVICES=devs, **extra),
+                            capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert rc.returncode == 0, rc.stderr
+        assert (tmp_path / "mid.json").read_text() == zk.proof_to_json(want_pts, "rapidsnark")
+
+
 @pytest.mark.parametrize("fail", ["2:1", "0:2", "3:3"])
 def test_a_failing_rank_ends_the_multi_rank_proof_with_an_error_not_a_hang(zk, tmp_path, fail):
     """One rank of a four-rank proof fails (test hook) before the first barrier, between the two exchanges or before its

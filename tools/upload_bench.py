@@ -78,14 +78,18 @@ def main():
             f.write(memoryview(blk[:min(left, blk.size)]))
             left -= blk.size
     try:
-        for threads, streams, aff in ((8, 0, ""), (8, 1, ""), (8, 3, ""), (8, 7, ""), (16, 3, ""), (16, 7, ""), (8, 3, "gpu"), (16, 7, "gpu")):
-            env = dict(os.environ, ZKPOA_UPLOAD_THREADS=str(threads), ZKPOA_UPLOAD_STREAMS=str(streams))
-            if aff:
-                env["ZKPOA_UPLOAD_AFFINITY"] = aff
+        variants = [(8, 0, {}), (8, 1, {}), (8, 3, {}), (8, 1, {"ZKPOA_UPLOAD_STREAM_PRIO": "high"}),
+                    (8, 3, {"ZKPOA_UPLOAD_STREAM_PRIO": "high"}),
+                    (8, 1, {"GPU_MAX_HW_QUEUES": "8"}), (8, 1, {"GPU_MAX_HW_QUEUES": "16"}), (8, 3, {"GPU_MAX_HW_QUEUES": "16"}),
+                    (8, 3, {"GPU_MAX_HW_QUEUES": "16", "ZKPOA_UPLOAD_STREAM_PRIO": "high"}),
+                    (8, 1, {"ZKPOA_UPLOAD_AFFINITY": "gpu"}), (12, 1, {}), (16, 1, {"GPU_MAX_HW_QUEUES": "16"})]
+        for threads, streams, extra in variants:
+            aff = " ".join("%s=%s" % kv for kv in extra.items())
+            env = dict(os.environ, ZKPOA_UPLOAD_THREADS=str(threads), ZKPOA_UPLOAD_STREAMS=str(streams), **extra)
             rc = subprocess.run([sys.executable, os.path.abspath(__file__), "--gb", str(args.gb), "--child", path], env=env,
                                 capture_output=True, text=True)
             line = [l for l in rc.stdout.splitlines() if l.startswith("{")]
-            print("threads %2d, own streams %d%s: %s" % (threads, streams, ", affinity " + aff if aff else "",
+            print("threads %2d, own streams %d%s: %s" % (threads, streams, ", " + aff if aff else "",
                                                           line[-1] if line else "FAILED " + rc.stderr[-400:]), flush=True)
     finally:
         os.remove(path)

@@ -165,7 +165,10 @@ struct DeviceCtx {
     bg_ = std::thread([this] {
       try {
         ZK_HIP(hipSetDevice(device));
-        hipError_t ce = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        // highest priority: a copy queued at normal priority waits behind the lanes' kernels (fast_upload.hpp)
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        hipError_t ce = hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, phi);
         if (ce != hipSuccess) copy_stream = nullptr;
         if (copy_stream && after_copy_stream) {
           try {

@@ -87,14 +87,26 @@ class FastUploader {
   // Streams of the uploader's own (ZKPOA_UPLOAD_STREAMS, default 3: four with the caller's). Called from the context's
   // background thread AFTER the lanes are up: a stream costs 10-50 ms to create, so a one-shot prover's first upload
   // (the witness) starts on the caller's stream alone and later sections find more streams as they appear.
+  // Their priority is HIGH: on this runtime a host -> device copy is queued like a kernel, and at normal priority it
+  // waits behind the lanes' kernels -- measured on an MI355X (tools/upload_bench.py, 8 GB from the page cache, four lanes
+  // running 2^22-point MSMs): 3 GB/s on three normal-priority streams, 12 GB/s on one, 34 GB/s on one high-priority
+  // stream (47 GB/s with the chip idle), 40 GB/s on three with GPU_MAX_HW_QUEUES=16 (which the `prover` executable sets
+  // for its own process: with the default of 4 hardware queues the eleven streams of a context share queues, and a
+  // copy then sits behind a kernel of the lane it shares with). Default: 1 own stream, 3 when GPU_MAX_HW_QUEUES >= 8.
   void add_streams(int device) {
-    int want = 3;
+    int want = 1;
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
+      if (atoi(q) >= 8) want = 3;
     if (const char* e = getenv("ZKPOA_UPLOAD_STREAMS")) want = atoi(e);
     if (want > kMaxOwnStreams) want = kMaxOwnStreams;
     for (int i = n_own_.load(); i < want; i++) {
       if (hipSetDevice(device) != hipSuccess) return;
       hipStream_t st = nullptr;
-      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      int lo = 0, hi = 0;   // numerically lower = higher priority
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      const char* pe = getenv("ZKPOA_UPLOAD_STREAM_PRIO");
+      const int prio = pe && !strcmp(pe, "normal") ? (lo + hi) / 2 : pe && !strcmp(pe, "low") ? lo : hi;
+      if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) {
         (void)hipGetLastError();
         return;
       }
@@ -133,7 +145,7 @@ class FastUploader {
   void* block_ = nullptr;
   bool ready_ = false;
   int threads_ = 8;
-  cpu_set_t cpus_;            // ZKPOA_UPLOAD_AFFINITY=gpu: the CPUs of the GPU's NUMA node (staging copies stay on its socket)
+  cpu_set_t cpus_;            // the CPUs of the GPU's NUMA node (staging copies stay on its socket)
   bool have_cpus_ = false;
   static constexpr int kMaxOwnStreams = 8;
   hipStream_t own_[kMaxOwnStreams] = {};
@@ -206,8 +218,12 @@ class FastUploader {
     unsigned hw = std::thread::hardware_concurrency();
     if (hw && (int)hw < threads_) threads_ = (int)hw;
     ZK_HIP(hipSetDevice(device));
-    if (const char* e = getenv("ZKPOA_UPLOAD_AFFINITY"))
-      if (!strcmp(e, "gpu")) have_cpus_ = gpu_node_cpus(device, &cpus_);
+    // the staging threads (and the first touch of their pinned buffers) stay on the CPUs of the GPU's NUMA node: 51 vs
+    // 47 GB/s on a two-socket box (ZKPOA_UPLOAD_AFFINITY=off: wherever the scheduler puts them)
+    {
+      const char* e = getenv("ZKPOA_UPLOAD_AFFINITY");
+      if (!e || strcmp(e, "off") != 0) have_cpus_ = gpu_node_cpus(device, &cpus_);
+    }
     cpu_set_t before;
     const bool moved = have_cpus_ && pthread_getaffinity_np(pthread_self(), sizeof(before), &before) == 0 &&
                        pthread_setaffinity_np(pthread_self(), sizeof(cpus_), &cpus_) == 0;

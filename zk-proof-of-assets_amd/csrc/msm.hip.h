@@ -902,6 +902,7 @@ struct MsmSorted {
   uint32_t* order = nullptr;    // piece ids, longest first
   uint32_t* pbkt = nullptr;     // piece -> bucket
   uint32_t total1 = 0;          // level-0 pieces
+  uint32_t total_entries = 0;   // (point, window) entries with a non-zero digit = mixed additions of the level-0 kernel
   uint32_t max_count = 0;       // largest bucket
 };
 
@@ -1055,6 +1056,7 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   }
   uint32_t* hb = reinterpret_cast<uint32_t*>(lane.pinned);
   msm_read_back(lane, misc, 16);
+  sr.total_entries = hb[0];
   sr.max_count = hb[1];
   sr.total1 = hb[2];
   if (sr.total1) {
@@ -1290,11 +1292,13 @@ inline void msm_table_free(MsmTable& t) {
 // n bases) the fixed-base form runs: d_bases is then not read.
 template <class F>
 inline MsmPlan msm_device(Lane& lane, const void* d_bases, const void* d_scalars, size_t n, void* window_sums_host,
-                          int force_c = 0, float* accum_ms = nullptr, const MsmTable* table = nullptr) {
+                          int force_c = 0, float* accum_ms = nullptr, const MsmTable* table = nullptr,
+                          uint32_t* entries = nullptr) {
   if (table && table->n != n) throw HipError("msm: the fixed-base table was built for another base array");
   MsmSorted sr = msm_sort_phase(lane, d_scalars, n, table ? (int)table->c : force_c, &msm_accum_workspace_bytes<F>,
                                 false, FieldBytes<F>::N > 32, table != nullptr);
   msm_accum_phase<F>(lane, sr, table ? table->d : d_bases, window_sums_host, true, accum_ms);
+  if (entries) *entries = sr.total_entries;
   return sr.p;
 }
 

@@ -19,14 +19,16 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   if (table && (n > max_pts || table->n != n)) table = nullptr;   // a chunked MSM cannot index a whole-array table
   XYZZ<HF> total = XYZZ<HF>::inf();
   float tot_ms = 0, acc_sum = 0;
-  uint64_t done = 0;
+  uint64_t done = 0, adds = 0;
   do {
     const uint64_t cnt = n - done < max_pts ? n - done : max_pts;
     float acc_ms = 0;
+    uint32_t entries = 0;
     ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
     MsmPlan p = msm_device<F>(lane, reinterpret_cast<const char*>(d_bases) + done * MsmSizes<F>::kAffine,
                               reinterpret_cast<const char*>(d_scalars) + done * 32, (size_t)cnt, wsums.data(),
-                              ctx->opt_msm_c, &acc_ms, table);
+                              ctx->opt_msm_c, &acc_ms, table, &entries);
+    adds += entries;
     ZK_HIP(hipEventRecord(ctx->ev_b[lane_id], lane.stream));
     ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));
     float tot = 0;
@@ -42,6 +44,7 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
     ms2[0] = tot_ms;
     ms2[1] = acc_sum;
   }
+  ctx->lane_adds[lane_id] = (double)adds;
   h_affine_to_bytes<HF>(h_to_affine(total), out);
 }
 
@@ -64,6 +67,7 @@ void msm_accum_run(zkpoa_context* ctx, int lane_id, const MsmSorted& sr, bool ow
     ms2[0] = tot;
     ms2[1] = acc_ms;
   }
+  ctx->lane_adds[lane_id] = (double)sr.total_entries;
   XYZZ<HF> r = h_combine_windows<HF>(wsums.data(), sr.p.Wb, sr.p.c, sr.p.logS);
   h_affine_to_bytes<HF>(h_to_affine(r), out);
 }

@@ -566,6 +566,11 @@ static int client_main(char** argv, const std::string& sock, bool stop) {
 
 int main(int argc, char** argv) {
   const double t_start = now_ms();
+  // This process's HIP runtime (loaded later, on demand; the resident server is a child of this process and inherits
+  // it): a context has eleven streams -- six lanes, the copy stream, the uploader's own, the null stream -- and with the
+  // default of four hardware queues they share queues, so an upload that should overlap the compute sits behind a
+  // lane's kernels. Never overrides the caller's own setting.
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   const char* srv = getenv("ZKPOA_SERVER");
   const bool use_server = srv && *srv && strcmp(srv, "0") != 0;
   if (argc == 2 && strcmp(argv[1], "--stop-server") == 0) {

@@ -153,7 +153,8 @@ extern "C" int zkpoa_msm_g1_device_lane(zkpoa_context* ctx, int lane, const void
 }
 
 extern "C" float zkpoa_last_ms_lane(const zkpoa_context* ctx, int lane, int id) {
-  if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes || id < 0 || id > 1) return -1.f;
+  if (!ctx || lane < 0 || lane >= DeviceCtx::kLanes || id < 0 || id > 2) return -1.f;
+  if (id == 2) return (float)(ctx->lane_adds[lane] * 1e-6);   // millions of mixed additions (float: 24-bit mantissa)
   return ctx->lane_ms[lane][id];
 }
 

@@ -24,6 +24,7 @@ struct zkpoa_context {
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float io_ms[2] = {0, 0};   // last prove from a host buffer: [0] witness -> HBM (host clock), [1] its bytes / 1e6
   float lane_ms[zkpoa::DeviceCtx::kLanes][2] = {};   // per-lane {whole MSM, accumulation kernel} of the last MSM
+  double lane_adds[zkpoa::DeviceCtx::kLanes] = {};   // per-lane mixed additions of that kernel (non-zero digits)
   int opt_msm_c = 0;
   long opt_msm_max_points = 0;   // 0 = default (2^27): larger MSMs run in chunks
   int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
