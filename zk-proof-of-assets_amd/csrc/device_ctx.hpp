@@ -118,7 +118,7 @@ struct DeviceCtx {
   int device = 0;
   int num_cu = 256;
   static constexpr int kLanes = 12;      // lanes a caller may address (zkpoa_msm_g1_device_lane ...)
-  static constexpr int kEagerLanes = 6;  // created with the context (the prover uses 0-4); the rest on first use
+  static constexpr int kEagerLanes = 5;  // created with the context (the prover uses 0-4); the rest on first use
   Lane lanes[kLanes];
   std::mutex lazy_mutex_;
   bool ok = false;
@@ -126,6 +126,8 @@ struct DeviceCtx {
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::thread bg_;
   std::mutex bg_mutex_;
+  std::condition_variable bg_cv_;
+  bool lanes_ready_ = false;     // lanes 1 .. kEagerLanes-1 exist (or bg_err_ says why not); extras may still be coming up
   std::exception_ptr bg_err_;
   // A stream of its own for host -> HBM copies that run WHILE lanes compute (one-shot proves overlap the zkey upload
   // with the MSMs). First thing the background thread creates; copy_stream_wait() blocks until it exists.
@@ -191,12 +193,6 @@ struct DeviceCtx {
         static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1}, kTop1[6] = {2, 1, 1, 0, 0, 0};
         for (int i = 1; i < kEagerLanes; i++)
           lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : top1 ? kTop1[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
-        if (after_lanes) {
-          try {
-            after_lanes();
-          } catch (...) {   // extras only
-          }
-        }
       } catch (...) {
         bg_err_ = std::current_exception();
         {
@@ -204,6 +200,18 @@ struct DeviceCtx {
           copy_done_ = true;
         }
         copy_cv_.notify_all();
+      }
+      {
+        std::lock_guard<std::mutex> lk(bg_mutex_);
+        lanes_ready_ = true;
+      }
+      bg_cv_.notify_all();
+      // extras nobody waits for (the uploader's own streams: ~10-50 ms each, and a one-shot layer-one proof is 190 ms)
+      if (!bg_err_ && after_lanes) {
+        try {
+          after_lanes();
+        } catch (...) {
+        }
       }
     });
     if (verbose)
@@ -228,20 +236,21 @@ struct DeviceCtx {
   }
   // every lane other than 0 may only be used after this (cheap once the background thread has been joined)
   void wait_lanes() {
-    std::lock_guard<std::mutex> lk(bg_mutex_);
-    if (bg_.joinable()) bg_.join();
+    std::unique_lock<std::mutex> lk(bg_mutex_);
+    bg_cv_.wait(lk, [this] { return lanes_ready_; });
     if (bg_err_) {
       std::exception_ptr e = bg_err_;
       bg_err_ = nullptr;
       std::rethrow_exception(e);
     }
   }
+  // the background thread has ended (extras included): before anything it touches is torn down
+  void join_background() {
+    if (bg_.joinable()) bg_.join();
+  }
   void destroy() {
     if (!ok) return;
-    try {
-      wait_lanes();
-    } catch (...) {
-    }
+    join_background();
     (void)hipSetDevice(device);
     for (auto& l : lanes) l.destroy();
     if (copy_stream) (void)hipStreamDestroy(copy_stream);

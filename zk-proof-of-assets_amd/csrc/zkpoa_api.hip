@@ -54,10 +54,7 @@ extern "C" void zkpoa_context_destroy(zkpoa_context* ctx) {
   }
   ntt_release(ctx);
   poseidon_release(ctx);
-  try {
-    ctx->dev.wait_lanes();   // the background thread may still be adding the uploader's streams
-  } catch (...) {
-  }
+  ctx->dev.join_background();   // it may still be adding the uploader's streams
   ctx->uploader.release();
   ctx->dev.destroy();
   delete ctx;
