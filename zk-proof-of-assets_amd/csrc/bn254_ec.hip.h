@@ -10,6 +10,7 @@
 // The curve coefficient a is 0 for both groups, so no formula below needs b.
 #pragma once
 #include "bn254_field.hip.h"
+#include <type_traits>
 
 #define ZK_HD __host__ __device__ __forceinline__
 
@@ -78,6 +79,32 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& p_in, bool negate) {
     acc = {p.x, p.y, F::one(), F::one()};
     return;
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKPOA_G1_UNPAIRED)
+  // r04: the independent products of the G1 addition taken in pairs (Fq::mul_pair, two accumulator chains in lockstep):
+  // u2 | s2, pp | r^2, ppp | q, r (q - x3) | y ppp, zz pp | zzz ppp. Same instructions and registers (149 VGPRs in the
+  // accumulation kernel); the register-only loop gains 1.4 % at three waves per SIMD, 10 % at one (tools/microbench4.hip;
+  // -DZKPOA_G1_UNPAIRED builds the r03 form).
+  if constexpr (std::is_same<F, Fq>::value) {
+    F u2, s2;
+    Fq::mul_pair(p.x, acc.zz, p.y, acc.zzz, u2, s2);
+    F pp_ = u2 - acc.x;
+    F r = s2 - acc.y;
+    if (pp_.is_zero()) {
+      if (r.is_zero()) acc = xyzz_dbl_affine(p);
+      else acc = XYZZ<F>::inf();
+      return;
+    }
+    F pp, rr, ppp, q, t0, t1;
+    Fq::sqr_pair(pp_, r, pp, rr);
+    Fq::mul_pair(pp_, pp, acc.x, pp, ppp, q);
+    F x3 = rr - ppp - q.dbl();
+    Fq::mul_pair(r, q - x3, acc.y, ppp, t0, t1);
+    acc.x = x3;
+    acc.y = t0 - t1;
+    Fq::mul_pair(acc.zz, pp, acc.zzz, ppp, acc.zz, acc.zzz);
+    return;
+  }
+#endif
   F u2 = p.x * acc.zz;
   F s2 = p.y * acc.zzz;
   F pp_ = u2 - acc.x;

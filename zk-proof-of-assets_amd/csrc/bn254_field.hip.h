@@ -69,6 +69,21 @@ ZK_DEV void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
       : "vcc");
 }
 
+// two such accumulators advanced together: the second carry travels in an SGPR pair, so the two mads issue back to
+// back and neither addc waits for the other chain (a wave's own issue rate is what limits the multiplier at two waves
+// per SIMD -- the G2 kernels: tools/microbench4.hip, +6 % per Fq2 product there, nothing at eight waves)
+ZK_DEV void mac96x2(uint64_t& lo0, uint32_t& hi0, uint32_t a0, uint32_t b0, uint64_t& lo1, uint32_t& hi1, uint32_t a1,
+                    uint32_t b1) {
+  uint64_t c1;
+  asm("v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_mad_u64_u32 %2, %4, %7, %8, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_addc_co_u32 %3, %4, 0, %3, %4"
+      : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1), "=&s"(c1)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1)
+      : "vcc");
+}
+
 template <class PRM>
 struct Fp {
   uint32_t l[8];
@@ -271,6 +286,125 @@ struct Fp {
     }
     return reduce_2p(r);
   }
+  // (a0 b0 + a1 b1, c0 d0 + c1 d1): two dot2 advanced column by column in lockstep (mac96x2) -- the two coordinates
+  // of an Fq2 product
+  static ZK_DEV void dot2_pair(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, const Fp& c0, const Fp& d0,
+                               const Fp& c1, const Fp& d1, Fp& r0, Fp& r1) {
+    uint64_t lo0 = 0, lo1 = 0;
+    uint32_t hi0 = 0, hi1 = 0, m0[8], m1[8];
+    Fp x, y;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        mac96x2(lo0, hi0, a0.l[i], b0.l[k - i], lo1, hi1, c0.l[i], d0.l[k - i]);
+        mac96x2(lo0, hi0, a1.l[i], b1.l[k - i], lo1, hi1, c1.l[i], d1.l[k - i]);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      m0[k] = (uint32_t)lo0 * PRM::INV;
+      m1[k] = (uint32_t)lo1 * PRM::INV;
+      mac96x2(lo0, hi0, m0[k], PRM::P[0], lo1, hi1, m1[k], PRM::P[0]);
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) {
+        mac96x2(lo0, hi0, a0.l[i], b0.l[k - i], lo1, hi1, c0.l[i], d0.l[k - i]);
+        mac96x2(lo0, hi0, a1.l[i], b1.l[k - i], lo1, hi1, c1.l[i], d1.l[k - i]);
+      }
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      x.l[k - 8] = (uint32_t)lo0;
+      y.l[k - 8] = (uint32_t)lo1;
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+    r0 = reduce_2p(x);
+    r1 = reduce_2p(y);
+  }
+  // (a b, c d): two independent Montgomery products in lockstep (results < 2p, as operator*)
+  static ZK_DEV void mul_pair(const Fp& a, const Fp& b, const Fp& c, const Fp& d, Fp& r0, Fp& r1) {
+    uint64_t lo0 = 0, lo1 = 0;
+    uint32_t hi0 = 0, hi1 = 0, m0[8], m1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) mac96x2(lo0, hi0, a.l[i], b.l[k - i], lo1, hi1, c.l[i], d.l[k - i]);
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      m0[k] = (uint32_t)lo0 * PRM::INV;
+      m1[k] = (uint32_t)lo1 * PRM::INV;
+      mac96x2(lo0, hi0, m0[k], PRM::P[0], lo1, hi1, m1[k], PRM::P[0]);
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96x2(lo0, hi0, a.l[i], b.l[k - i], lo1, hi1, c.l[i], d.l[k - i]);
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      r0.l[k - 8] = (uint32_t)lo0;
+      r1.l[k - 8] = (uint32_t)lo1;
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+  }
+  // (a^2, b^2): two dedicated squarings (see sqr()) in lockstep
+  static ZK_DEV void sqr_pair(const Fp& a, const Fp& b, Fp& r0, Fp& r1) {
+    uint32_t al[8], ad[8], bl[8], bd[8];
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      al[j] = a.l[j] << 1;
+      ad[j] = __builtin_amdgcn_alignbit(a.l[j], a.l[j - 1], 31);
+      bl[j] = b.l[j] << 1;
+      bd[j] = __builtin_amdgcn_alignbit(b.l[j], b.l[j - 1], 31);
+    }
+    uint64_t lo0 = 0, lo1 = 0;
+    uint32_t hi0 = 0, hi1 = 0, m0[8], m1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++)
+        mac96x2(lo0, hi0, a.l[i], (k - i == i + 1) ? al[k - i] : ad[k - i], lo1, hi1, b.l[i], (k - i == i + 1) ? bl[k - i] : bd[k - i]);
+      if ((k & 1) == 0) mac96x2(lo0, hi0, a.l[k / 2], a.l[k / 2], lo1, hi1, b.l[k / 2], b.l[k / 2]);
+#pragma unroll
+      for (int i = 0; i < k; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      m0[k] = (uint32_t)lo0 * PRM::INV;
+      m1[k] = (uint32_t)lo1 * PRM::INV;
+      mac96x2(lo0, hi0, m0[k], PRM::P[0], lo1, hi1, m1[k], PRM::P[0]);
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+      for (int i = k - 7; 2 * i < k; i++)
+        mac96x2(lo0, hi0, a.l[i], (k - i == i + 1) ? al[k - i] : ad[k - i], lo1, hi1, b.l[i], (k - i == i + 1) ? bl[k - i] : bd[k - i]);
+      if ((k & 1) == 0 && k / 2 < 8) mac96x2(lo0, hi0, a.l[k / 2], a.l[k / 2], lo1, hi1, b.l[k / 2], b.l[k / 2]);
+#pragma unroll
+      for (int i = k - 7; i < 8; i++) mac96x2(lo0, hi0, m0[i], PRM::P[k - i], lo1, hi1, m1[i], PRM::P[k - i]);
+      r0.l[k - 8] = (uint32_t)lo0;
+      r1.l[k - 8] = (uint32_t)lo1;
+      lo0 = (lo0 >> 32) | ((uint64_t)hi0 << 32);
+      hi0 = 0;
+      lo1 = (lo1 >> 32) | ((uint64_t)hi1 << 32);
+      hi1 = 0;
+    }
+  }
   ZK_DEV Fp neg_2p() const {  // 2p - a in [1, 2p] (no zero test): only as an operand of dot2
     Fp r;
     uint32_t bw = 0;
@@ -326,13 +460,20 @@ struct Fq2 {
   // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, each coordinate ONE lazily reduced sum of two
   // products (Fq::dot2): 2 x (128 + 72) mad pairs and two conditional subtractions. The Karatsuba form it replaces
   // (3 x 136 pairs + 5 additions / subtractions of 24 instructions each) was 10 % more instructions.
+  // r04: the two coordinates advance in lockstep (Fq::dot2_pair), which at the two waves per SIMD of the G2 kernels is
+  // worth +6 % per product (tools/microbench4.hip); same instructions, three more registers.
   friend ZK_DEV Fq2 operator*(const Fq2& a, const Fq2& b) {
-    return {Fq::dot2(a.c0, b.c0, a.c1, b.c1.neg_2p()), Fq::dot2(a.c0, b.c1, a.c1, b.c0)};
+    Fq2 r;
+    Fq::dot2_pair(a.c0, b.c0, a.c1, b.c1.neg_2p(), a.c0, b.c1, a.c1, b.c0, r.c0, r.c1);
+    return r;
   }
-  // (a0+a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u
+  // (a0+a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u: two independent products, in lockstep too
   ZK_DEV Fq2 sqr() const {
-    Fq t = c0 * c1;
-    return {(c0 + c1) * (c0 - c1), t + t};
+    Fq2 r;
+    Fq t;
+    Fq::mul_pair(c0 + c1, c0 - c1, c0, c1, r.c0, t);
+    r.c1 = t + t;
+    return r;
   }
   ZK_DEV Fq2 inv() const {
     Fq d = (c0.sqr() + c1.sqr()).inv();
