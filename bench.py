@@ -575,9 +575,9 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
             # rate, not the pipe, sets the pace
             roof["valu_accum"] = {
                 x: {"kernel_ms_solo": accum[x][0], "mixed_additions_M": accum[x][1],
-                    "achieved_Gadds": accum[x][1] / accum[x][0] * 1e-3 if accum[x][0] > 0 else None,
+                    "achieved_Gadds": accum[x][1] / accum[x][0] if accum[x][0] > 0 else None,   # millions per ms = G/s
                     "peak_Gadds": G2_VALU_PEAK_GADDS if x == "B2" else VALU_PEAK_GADDS,
-                    "frac": (accum[x][1] / accum[x][0] * 1e-3 / (G2_VALU_PEAK_GADDS if x == "B2" else VALU_PEAK_GADDS))
+                    "frac": (accum[x][1] / accum[x][0] / (G2_VALU_PEAK_GADDS if x == "B2" else VALU_PEAK_GADDS))
                             if accum[x][0] > 0 else None}
                 for x in names}
             tot = sum(solo.values())

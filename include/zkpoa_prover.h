@@ -81,6 +81,16 @@ int zkpoa_groth16_prover_files(const char* zkey_file_path, const char* wtns_file
 int zkpoa_set_thread_options(const char* r_decimal, const char* s_decimal, const char* json_style, int verbose);
 int zkpoa_clear_thread_options(void);
 
+/* "The host has nothing to do right now." groth16_prover_zkey_file / zkpoa_groth16_prover_files keep keys resident
+ * (env ZKPOA_KEY_CACHE) and prove ~10 % faster once a key has its fixed-base tables, but building them is seconds of GPU
+ * time at the layer-two / -three sizes -- so by default (ZKPOA_PRECOMP unset or "idle") that never happens inside a
+ * request: each call of zkpoa_idle_work builds ONE table of the most recently used key that still lacks some and returns
+ * 1 (call again while idle), or returns 0 at once when there is nothing to do or a request is in flight. The `prover`
+ * server calls it after 300 ms without a request. A host that never calls it gets the whole set built inside the request
+ * that follows a key's ZKPOA_PRECOMP_AFTER-th proof (default 64). ZKPOA_PRECOMP=eager: at the second use, inside the
+ * request (r03); =0: never. */
+int zkpoa_idle_work(void);
+
 /* ---- context ----------------------------------------------------------------------------- */
 typedef struct zkpoa_context zkpoa_context;
 typedef struct zkpoa_zkey zkpoa_zkey;
@@ -206,7 +216,7 @@ int zkpoa_split_stage3(zkpoa_context* ctx, const zkpoa_zkey* zkey, void* d_recei
 /* Fixed-base tables for a resident key (zkpoa_msm_table_build applied to sections 9, 8 and the A / B queries, in
  * that order while they fit budget_bytes; 0 = half of the HBM free at the call). Later proves on the handle use
  * them; proofs are bit-identical with and without. groth16_prover_zkey_file's key cache does this by itself the
- * second time a key is used (env ZKPOA_PRECOMP=0 disables). used_bytes (optional) <- HBM taken by the tables.
+ * second time a key is used only with env ZKPOA_PRECOMP=eager; by default from zkpoa_idle_work (below: never inside a request). used_bytes (optional) <- HBM taken by the tables.
  * A shard handle (zkpoa_zkey_load_shard*, _load_device_shard) gets the tables of its own ranges -- 1/world of the
  * memory per GPU -- incl. the cyclic H shard of a split handle; a resident key re-pointed with zkpoa_zkey_set_shard*
  * uses its tables only while its range is the whole array they were built from. */

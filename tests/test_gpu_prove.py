@@ -340,7 +340,9 @@ def test_prover_cli_several_ranks_mid_size_server_and_errors(zk, tmp_path, mid_c
     assert rc.returncode == 0, rc.stderr
     want = (tmp_path / "single.json").read_text()
     sock = str(tmp_path / "prover.sock")
-    env = dict(base, ZKPOA_DEVICES="0,0,0,0", ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60")
+    # (ZKPOA_PRECOMP=eager: the tables on the key's second use, inside the request -- the r03 policy; the default builds
+    # them from the server's idle time, test_server_builds_tables_in_its_idle_time_not_in_a_request)
+    env = dict(base, ZKPOA_DEVICES="0,0,0,0", ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60", ZKPOA_PRECOMP="eager")
     try:
         for i in range(3):
             rc = subprocess.run(argv("multi%d" % i), env=env, capture_output=True, text=True, cwd=tmp_path, timeout=300)
@@ -518,6 +520,44 @@ def test_prover_cli_server_mode(zk, tmp_path):
             break
         time.sleep(0.05)
     assert not os.path.exists(sock)
+
+
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_server_builds_tables_in_its_idle_time_not_in_a_request(zk, tmp_path, mid_circuit, devices):
+    """Default policy (ZKPOA_PRECOMP unset): a resident key's fixed-base tables are never built inside a request -- a whole
+    set is seconds at the layer-two / -three sizes, which a two-batch workflow never earns back -- but one table per step
+    from the server's idle time (zkpoa_idle_work, after ZKPOA_SERVER_IDLE_WORK_MS without a request). First call: load;
+    then the server is left alone for a moment; the following calls are plain cache hits whose proofs -- now through the
+    tables -- are byte-identical."""
+    zkey, vk, wt, n_pub = mid_circuit
+    (tmp_path / "circuit_final.zkey").write_bytes(zkey)
+    (tmp_path / "witness.wtns").write_bytes(wt)
+    sock = str(tmp_path / "prover.sock")
+    env = dict(os.environ, ZKPOA_R="12345678901234567890", ZKPOA_S="98765432109876543210", ZKPOA_VERBOSE="1",
+               ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60", ZKPOA_SERVER_IDLE_WORK_MS="100")
+    env.pop("ZKPOA_PRECOMP", None)
+    if devices:
+        env["ZKPOA_DEVICES"] = devices
+    argv = lambda out: [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", out + ".json", out + "_public.json"]
+    try:
+        rc = subprocess.run(argv("p0"), env=env, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert rc.returncode == 0, rc.stderr
+        log = ""
+        for _ in range(100):                                   # the idle work starts by itself
+            time.sleep(0.1)
+            log = (tmp_path / "prover.sock.log").read_text()
+            if ("complete)" in log) if not devices else ("idle: fixed-base tables for the cached key on 2 ranks" in log):
+                break
+        assert "zkpoa: idle: fixed-base table" in log, log
+        for i in (1, 2):
+            rc = subprocess.run(argv("p%d" % i), env=env, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+            assert rc.returncode == 0, rc.stderr
+            assert (tmp_path / ("p%d.json" % i)).read_text() == (tmp_path / "p0.json").read_text()
+        log = (tmp_path / "prover.sock.log").read_text()
+        assert log.count("| zkey cached,") == 2
+        assert "fixed-base tables for the cached key:" not in log and "fixed-base tables for the cached key on" not in log.replace("idle: fixed-base tables for the cached key on", "")
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
 
 
 def test_server_overlaps_requests_without_mixing_them_up(zk, tmp_path):

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): collects the evidence committed under profiles/ for this round (ROUND=r02 ...).
 # kernel stats and PMC counters are separate rocprofv3 runs (never combined), one PMC counter per pass.
 set -u
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profiles_$ROUND
 PART=${PART:-all}      # 1 = bench lines + kernel stats, 2 = PMC passes (a gpurun call is at most 20 minutes)

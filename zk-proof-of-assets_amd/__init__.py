@@ -31,7 +31,7 @@ EXPORTS = [
     "zkpoa_context_create", "zkpoa_context_destroy", "zkpoa_last_error",
     "zkpoa_zkey_load", "zkpoa_zkey_free", "zkpoa_zkey_info", "zkpoa_prove",
     "zkpoa_zkey_load_device", "zkpoa_zkey_load_device_shard", "zkpoa_prove_device", "zkpoa_setup_accumulate", "zkpoa_zkey_new", "zkpoa_zkey_contribute", "zkpoa_wtns_check",
-    "zkpoa_groth16_prover_files", "zkpoa_set_thread_options", "zkpoa_clear_thread_options", "zkpoa_zkey_load_shard", "zkpoa_zkey_load_shard_ex", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
+    "zkpoa_groth16_prover_files", "zkpoa_set_thread_options", "zkpoa_clear_thread_options", "zkpoa_idle_work", "zkpoa_zkey_load_shard", "zkpoa_zkey_load_shard_ex", "zkpoa_zkey_set_shard", "zkpoa_zkey_header",
     "zkpoa_prove_partials", "zkpoa_prove_partials_device", "zkpoa_prove_assemble",
     "zkpoa_zkey_load_shard_split", "zkpoa_zkey_set_shard_split", "zkpoa_witness_load",
     "zkpoa_split_stage1", "zkpoa_split_stage2", "zkpoa_split_stage3",

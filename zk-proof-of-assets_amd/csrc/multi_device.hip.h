@@ -270,6 +270,7 @@ struct MultiKey {
   std::vector<hipEvent_t> evw;              // per rank: "my slice of the witness is on its way to every peer"
   uint64_t xbytes = 0;                      // bytes of one exchange buffer: 3 * (domain / G) * 32
   uint64_t proofs_done = 0, table_bytes = 0;
+  bool tables_tried = false;                // the shards' fixed-base tables have been built (or the attempt has been made)
   double load_ms = 0;
 };
 

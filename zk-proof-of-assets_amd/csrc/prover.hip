@@ -207,6 +207,9 @@ struct zkpoa_zkey {
   MsmTable *tA = nullptr, *tB1 = nullptr, *tB2 = nullptr, *tC = nullptr, *tH = nullptr;
   bool tH_cyclic = false;     // tH was built from the cyclic shard dHs (split handles), not from dH
   uint64_t table_bytes = 0;
+  // incremental build (zkey_precompute_step: one table per call, from the resident prover's idle time)
+  uint64_t table_budget = 0;  // fixed at the first step (half of the HBM free then)
+  bool tables_settled = false;   // every table that is wanted and fits has been built (or an attempt failed)
   // digit density of the last witness measured on this handle (msm_density: non-zero digits per scalar for every
   // window width). A circuit's witnesses all look alike (bits stay bits), so it is measured by the first proof only
   // and sizes the windows of later proofs and of the witness tables (zkey_precompute after a proof).
@@ -220,6 +223,8 @@ struct zkpoa_zkey {
     }
     table_bytes = 0;
     tH_cyclic = false;
+    table_budget = 0;
+    tables_settled = false;
   }
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
@@ -833,24 +838,39 @@ bool split_h_partial(const zkpoa_zkey* zk) {
 // that is free right now -- which leaves room for the per-lane sort / bucket workspaces). H and C first: the H MSM
 // closes the critical path and section 8 is the largest G1 array; then the A query; the B query needs both its
 // G1 and G2 table (they share one bucket sort). Returns the bytes allocated.
-uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
+// max_new < 0: all of them at once, replacing what exists (zkpoa_zkey_precompute, the eager policy). max_new >= 0: keep
+// what exists and build at most that many more -- the resident prover builds a key's tables one per idle moment, so that
+// a request never waits for more than one of them (a whole set is 0.25 s at the layer-one shape, 3-7 s at layers two and
+// three: more than twenty proofs' worth, which a workflow of two batches never earns back on the request path).
+uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, int max_new = -1) {
   const bool split = zk->split_world > 1;   // H table over the cyclic shard; A / B / C as for any shard
   ctx->dev.wait_lanes();
   ZK_HIP(hipDeviceSynchronize());
-  zk->release_tables();
+  const bool step = max_new >= 0;
+  int built = 0;
+  bool deferred = false;
+  if (!step) zk->release_tables();
+  if (step && zk->table_budget) budget = zk->table_budget;
   if (budget == 0) {
     // the lanes' grow-only workspaces are given back first (they regrow to what the fixed-base plans need)
     for (auto& l : ctx->dev.lanes) l.ws.release();
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-    budget = (uint64_t)(0.5 * (double)free_b);
+    budget = (uint64_t)(0.5 * (double)free_b) + zk->table_bytes;
   }
+  if (step) zk->table_budget = budget;
   const int force_c = ctx->opt_msm_c;
   auto fits = [&](uint64_t bytes) { return zk->table_bytes + bytes <= budget; };
   const uint64_t nH = split ? (zk->dHs ? (uint64_t)(zk->domain >> zk->split_log) : 0) : (zk->dH ? zk->hcnt : 0);
   const uint64_t nC = zk->ccnt, nA = zk->qA.res, nB = zk->qB.res;
   // a table that does not fit after all (allocation failure) ends the list; the ones built so far stay
   auto build = [&](MsmTable** slot, bool g2, const void* bases, uint64_t n, int c) -> bool {
+    if (*slot) return true;                     // (step mode: built by an earlier step)
+    if (step && built >= max_new) {             // this step's share is done: the rest waits for the next step
+      deferred = true;
+      return false;
+    }
+    built++;
     try {
       *slot = g2 ? msm_table_build_g2(ctx, bases, n, c) : msm_table_build_g1(ctx, bases, n, c);
       zk->table_bytes += g2 ? msm_table_bytes_g2(n, c) : msm_table_bytes_g1(n, c);
@@ -872,17 +892,22 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
   };
   msm_set_density_hint(nullptr);
   bool more = true;
-  if (more && nH && (split || zk->hlo == zk->hbase) && fits(msm_table_bytes_g1(nH, force_c))) {
+  // (a table that exists already counts as fitting: its bytes are in table_bytes)
+  if (more && nH && (split || zk->hlo == zk->hbase) && (zk->tH || fits(msm_table_bytes_g1(nH, force_c)))) {
     more = build(&zk->tH, false, split ? zk->dHs : zk->dH, nH, force_c);
     zk->tH_cyclic = split && zk->tH;
   }
   const int cC = nC ? witness_c(nC, false) : 0, cA = nA ? witness_c(nA, false) : 0;
-  if (more && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, cC))) more = build(&zk->tC, false, zk->dC, nC, cC);
-  if (more && nA && fits(msm_table_bytes_g1(nA, cA))) more = build(&zk->tA, false, zk->qA.g1, nA, cA);
-  if (more && nB) {
+  if (more && nC && zk->clo == zk->cbase && (zk->tC || fits(msm_table_bytes_g1(nC, cC)))) more = build(&zk->tC, false, zk->dC, nC, cC);
+  if (more && nA && (zk->tA || fits(msm_table_bytes_g1(nA, cA)))) more = build(&zk->tA, false, zk->qA.g1, nA, cA);
+  if (more && nB && !(zk->tB1 && zk->tB2)) {
     // one window width for both B tables: the G2 model's (shorter pieces), as the shared sort is planned for G2
     const int cB = witness_c(nB, true);
-    if (fits(msm_table_bytes_g1(nB, cB) + msm_table_bytes_g2(nB, cB))) {
+    if (step && built >= max_new) {   // the pair is one step's work
+      more = false;
+      deferred = true;
+    } else if (fits(msm_table_bytes_g1(nB, cB) + msm_table_bytes_g2(nB, cB))) {
+      if (step) max_new = built + 2;              // ... and both halves belong to it
       more = build(&zk->tB1, false, zk->qB.g1, nB, cB) && build(&zk->tB2, true, zk->qB.g2, nB, cB);
       if (!more && zk->tB1) {   // the pair is only usable together
         zk->table_bytes -= msm_table_bytes_g1(nB, cB);
@@ -891,6 +916,8 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget) {
       }
     }
   }
+  // settled: nothing is left for a later step (every wanted table exists, does not fit, or failed to build)
+  zk->tables_settled = !deferred;
   return zk->table_bytes;
 }
 
@@ -1667,6 +1694,35 @@ int one_shot(const uint8_t* zkey, uint64_t zkey_size, const WtnsSrc& wsrc, char*
 // CSR each time is most of a call. Keyed by (device, inode, size, mtime): a rewritten file is a different key.
 // ZKPOA_KEY_CACHE = number of keys kept (default 2, 0 = off); least recently used goes first, and everything
 // goes when an upload runs out of HBM.
+// When a resident key gets its fixed-base tables (ZKPOA_PRECOMP). A whole set costs 0.25 s at the layer-one shape and
+// 3-7 s at layers two and three -- twenty to thirty proofs' worth -- and saves ~10 % per proof, so it pays after a few
+// hundred proofs. r02 / r03 built it on the request path at the key's SECOND use: a workflow of two batches
+// (tests/4_sigs_2_batches_12_height) then spent 3.4 s on a 0.12 s proof. r04 default ("idle"): never on the request path
+// -- zkpoa_idle_work builds one table per call when the library has nothing else to do (the `prover` server calls it
+// after 300 ms without a request) -- except for a key that has served ZKPOA_PRECOMP_AFTER proofs (default 64) in a host
+// that never calls it. "eager" = the r03 behaviour, "0" = never.
+enum PrecompPolicy { kPrecompOff, kPrecompEager, kPrecompIdle };
+PrecompPolicy precomp_policy() {
+  const char* e = getenv("ZKPOA_PRECOMP");
+  if (!e || !*e) return kPrecompIdle;
+  if (!strcmp(e, "0") || !strcmp(e, "off")) return kPrecompOff;
+  if (!strcmp(e, "eager")) return kPrecompEager;
+  return kPrecompIdle;
+}
+uint64_t precomp_after() {
+  const char* e = getenv("ZKPOA_PRECOMP_AFTER");
+  const long v = e && *e ? atol(e) : 64;
+  return v < 1 ? 1 : (uint64_t)v;
+}
+// must this request build the key's tables before it proves? (done = proofs the key has served, settled / bytes = its tables)
+bool tables_due_now(uint64_t done, bool settled, uint64_t bytes) {
+  switch (precomp_policy()) {
+    case kPrecompEager: return done == 1 && bytes == 0;
+    case kPrecompIdle: return done >= precomp_after() && !settled && bytes == 0;
+    default: return false;
+  }
+}
+
 struct CachedKey {
   dev_t dev;
   ino_t ino;
@@ -1758,11 +1814,11 @@ int multi_file_prove(DeviceSet* ds, int fd, const struct stat& sb, const char* p
         cached = true;
       }
     }
-    if (hit && mk->proofs_done == 1 && mk->table_bytes == 0) {
-      const char* e = getenv("ZKPOA_PRECOMP");
-      if (!e || strcmp(e, "0") != 0) {
+    if (hit && tables_due_now(mk->proofs_done, mk->tables_tried, mk->table_bytes)) {
+      {
         auto tp0 = std::chrono::steady_clock::now();
         multi_precompute(ds, mk);
+        mk->tables_tried = true;
         if (req_getenv("ZKPOA_VERBOSE"))
           fprintf(stderr, "zkpoa: fixed-base tables for the cached key on %zu ranks: %.2f GB in %.0f ms\n", ds->ids.size(),
                   mk->table_bytes / 1e9,
@@ -1894,16 +1950,12 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
   }
   zkpoa_context* ctx = ds->ctx[0];
   std::unique_lock<std::mutex> stage_lk(g_stage_mutex);
-  auto precomp_wanted = [] {
-    const char* e = getenv("ZKPOA_PRECOMP");
-    return !e || strcmp(e, "0") != 0;
-  };
   if (ds->ids.size() == 1) {   // steady state of a resident single-GPU key: stage the witness, then prove (two locks)
     for (auto& c : g_key_cache)
       if (c.dev == sb.st_dev && c.ino == sb.st_ino && c.size == sb.st_size && c.mtime.tv_sec == sb.st_mtim.tv_sec &&
           c.mtime.tv_nsec == sb.st_mtim.tv_nsec) {
         const uint64_t done = c.zk->proofs_done.load();
-        const bool tables_due = done == 1 && c.zk->table_bytes == 0 && precomp_wanted();
+        const bool tables_due = tables_due_now(done, c.zk->tables_settled, c.zk->table_bytes);
         hipStream_t cs = ctx->dev.copy_stream_wait();
         if (done >= 1 && !tables_due && cs) {
           c.last_use = ++g_key_clock;
@@ -1978,8 +2030,8 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
       else owned = true;
     }
     // a key that comes out of the cache is being reused: build its fixed-base tables now, once (ZKPOA_PRECOMP=0 off)
-    if (hit && !owned && zk->proofs_done == 1 && zk->table_bytes == 0) {
-      if (precomp_wanted()) {
+    if (hit && !owned && tables_due_now(zk->proofs_done, zk->tables_settled, zk->table_bytes)) {
+      {
         auto tp0 = std::chrono::steady_clock::now();
         try {
           uint64_t used = zkey_precompute(ctx, zk, 0);
@@ -1990,6 +2042,7 @@ int zkey_file_prove(const char* path, const WtnsSrc& wsrc, char* proof_buffer,
           zk->release_tables();
           (void)hipGetLastError();
         }
+        zk->tables_settled = true;
       }
     }
     if (!proved)
@@ -2595,4 +2648,60 @@ extern "C" int zkpoa_set_thread_options(const char* r_dec, const char* s_dec, co
 extern "C" int zkpoa_clear_thread_options(void) {
   req_options() = ReqOptions();
   return PROVER_OK;
+}
+
+// The host has nothing to do right now: the library may use the time. One step of background work per call -- today: the
+// next fixed-base table of the most recently used resident key that has none yet (ZKPOA_PRECOMP policy "idle") -- so that
+// a request arriving meanwhile waits for one table at most. Returns 1 when a step was done (call again while idle), 0
+// when there is nothing to do, the policy says no, or a request is in flight (never blocks behind one).
+extern "C" int zkpoa_idle_work(void) {
+  if (precomp_policy() != kPrecompIdle) return 0;
+  std::unique_lock<std::mutex> stage_lk(g_stage_mutex, std::try_to_lock);
+  if (!stage_lk.owns_lock() || g_staged_users) return 0;
+  std::unique_lock<std::mutex> lk(g_prove_mutex, std::try_to_lock);
+  if (!lk.owns_lock()) return 0;
+  DeviceSet* ds = nullptr;
+  {
+    std::lock_guard<std::mutex> dl(g_devset_mutex);
+    ds = g_devset;
+  }
+  if (!ds) return 0;
+  const bool verbose = getenv("ZKPOA_VERBOSE") != nullptr;
+  try {
+    if (ds->ids.size() > 1) {
+      for (auto& c : g_multi_cache)
+        if (c.mk->proofs_done >= 1 && c.mk->table_bytes == 0 && !c.mk->tables_tried) {
+          auto t0 = std::chrono::steady_clock::now();
+          c.mk->tables_tried = true;
+          multi_precompute(ds, c.mk);
+          if (verbose)
+            fprintf(stderr, "zkpoa: idle: fixed-base tables for the cached key on %zu ranks: %.2f GB in %.0f ms\n", ds->ids.size(),
+                    c.mk->table_bytes / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+          return 1;
+        }
+      return 0;
+    }
+    CachedKey* pick = nullptr;
+    for (auto& c : g_key_cache)
+      if (c.zk->proofs_done.load() >= 1 && !c.zk->tables_settled && (!pick || c.last_use > pick->last_use)) pick = &c;
+    if (!pick) return 0;
+    zkpoa_context* ctx = ds->ctx[0];
+    ZK_HIP(hipSetDevice(ctx->dev.device));
+    const uint64_t before = pick->zk->table_bytes;
+    auto t0 = std::chrono::steady_clock::now();
+    try {
+      (void)zkey_precompute(ctx, pick->zk, 0, 1);
+    } catch (const HipError&) {   // out of HBM: what exists stays, nothing more is tried
+      (void)hipGetLastError();
+      pick->zk->tables_settled = true;
+    }
+    if (verbose)
+      fprintf(stderr, "zkpoa: idle: fixed-base table step for the cached key: +%.2f GB in %.0f ms (%.2f GB so far%s)\n",
+              (pick->zk->table_bytes - before) / 1e9,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+              pick->zk->table_bytes / 1e9, pick->zk->tables_settled ? ", complete" : "");
+    return 1;
+  } catch (const std::exception&) {
+    return 0;
+  }
 }

@@ -45,6 +45,8 @@
 typedef int (*prover_files_fn)(const char*, const char*, char*, unsigned long*, char*, unsigned long*, char*, unsigned long);
 typedef int (*thread_options_fn)(const char*, const char*, const char*, int);
 static thread_options_fn g_set_thread_options = nullptr;   // per-request r, s, JSON style, verbosity of a server thread
+typedef int (*idle_work_fn)(void);
+static std::atomic<idle_work_fn> g_idle_work{nullptr};     // one step of the library's background work (fixed-base tables)
 static std::mutex g_load_mutex;
 static prover_files_fn load_prover(std::string& message) {
   static prover_files_fn fn = nullptr;
@@ -70,6 +72,7 @@ static prover_files_fn load_prover(std::string& message) {
   fn = reinterpret_cast<prover_files_fn>(dlsym(h, "zkpoa_groth16_prover_files"));
   if (!fn) message = "Error: libzkpoa_prover.so does not export zkpoa_groth16_prover_files";
   g_set_thread_options = reinterpret_cast<thread_options_fn>(dlsym(h, "zkpoa_set_thread_options"));
+  g_idle_work.store(reinterpret_cast<idle_work_fn>(dlsym(h, "zkpoa_idle_work")));
   return fn;
 }
 
@@ -264,6 +267,7 @@ static int connect_to(const std::string& sock) {
 }
 
 // The resident prover: serves requests one at a time (the GPU is the shared resource) until idle or told to stop.
+enum { kIdleJob = -2 };   // a queue entry that is not a connection: "run the library's idle work"
 static int server_main(const std::string& sock) {
   std::string lockp = sock + ".lock";
   int lock = open(lockp.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
@@ -297,6 +301,8 @@ static int server_main(const std::string& sock) {
   // Requests are served by a small pool of threads (ZKPOA_SERVER_WORKERS, default 2): the library stages the witness
   // of one request while it proves another (two locks inside zkpoa_groth16_prover_files), so the batch jobs the
   // reference runs in parallel (scripts/full_workflow.sh:552) do not pay the witness upload one after the other.
+  double idle_work_ms = 300;
+  if (const char* e = getenv("ZKPOA_SERVER_IDLE_WORK_MS")) idle_work_ms = atof(e) >= 0 ? atof(e) : idle_work_ms;
   int workers = 2;
   if (const char* e = getenv("ZKPOA_SERVER_WORKERS")) workers = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : workers;
   static const bool test_crash = getenv("ZKPOA_SERVER_TEST_CRASH") != nullptr;   // tests: die with a request in hand
@@ -311,7 +317,23 @@ static int server_main(const std::string& sock) {
   // leaving: the socket disappears BEFORE the answer goes out, so that the caller's next request finds no socket and
   // starts a fresh server instead of queueing behind one that is gone; the main loop is told after the answer is out
   auto leave = [&] { unlink(sock.c_str()); };
+  std::atomic<bool> idle_pending{false};   // a proof has been served since the library last said "nothing to do"
+  std::atomic<double> last_activity{now_ms()};   // a request arrived or a worker finished one
   auto serve = [&](int c) {
+    if (c == kIdleJob) {   // the server has been idle for a moment: the library's background work, one step at a time,
+      idle_work_fn f = g_idle_work.load();   // for as long as nobody is waiting
+      while (f && running.load()) {
+        {
+          std::lock_guard<std::mutex> lk(qm);
+          if (!queue.empty()) return;
+        }
+        if (f() == 0) {
+          idle_pending.store(false);
+          return;
+        }
+      }
+      return;
+    }
     {   // a client that connects and then says nothing must not hold a worker
       struct timeval tv = {10, 0};
       if (const char* e = getenv("ZKPOA_SERVER_RCV_TIMEOUT_S")) tv.tv_sec = atoi(e) > 0 ? atoi(e) : 10;
@@ -352,6 +374,7 @@ static int server_main(const std::string& sock) {
           g_set_thread_options(f[5].empty() ? nullptr : f[5].c_str(), f[6].empty() ? nullptr : f[6].c_str(),
                                f[7].empty() ? nullptr : f[7].c_str(), f[8].empty() ? 0 : 1);
         int rc = prove_files(f[1].c_str(), f[2].c_str(), f[3].c_str(), f[4].c_str(), message, &runtime_failure);
+        if (rc == EXIT_SUCCESS) idle_pending.store(true);
         if (rc == EXIT_SUCCESS && !f[8].empty())
           message = "zkpoa: prover server pid " + std::to_string((long)getpid()) + " served the proof in " +
                     std::to_string(now_ms() - t0) + " ms";
@@ -393,11 +416,11 @@ static int server_main(const std::string& sock) {
         {
           std::lock_guard<std::mutex> lk(qm);
           busy--;
+          if (c != kIdleJob) last_activity.store(now_ms());
         }
         qcv.notify_all();
       }
     });
-  double last_activity = now_ms();
   while (running.load()) {
     struct pollfd pfd[2] = {{ls, POLLIN, 0}, {wake[0], POLLIN, 0}};
     int pr = poll(pfd, wake[0] >= 0 ? 2 : 1, 200);   // (short slices all the same: the idle clock)
@@ -412,16 +435,19 @@ static int server_main(const std::string& sock) {
         }
         qcv.notify_one();
       }
-      last_activity = now_ms();
+      last_activity.store(now_ms());
       continue;
     }
     bool idle;
     {
       std::lock_guard<std::mutex> lk(qm);
       idle = busy == 0 && queue.empty();
-      if (!idle) last_activity = now_ms();
+      if (!idle) last_activity.store(now_ms());
+      // nothing to do for a moment: let the library use the GPU (fixed-base tables of the keys it keeps, one per step)
+      if (idle && idle_pending.load() && now_ms() - last_activity.load() >= idle_work_ms) queue.push_back(kIdleJob);
     }
-    if (idle && now_ms() - last_activity >= idle_s * 1e3) break;   // idle: give the HBM back
+    if (idle && idle_pending.load()) qcv.notify_one();
+    if (idle && now_ms() - last_activity.load() >= idle_s * 1e3) break;   // idle: give the HBM back
   }
   running.store(false);
   unlink(sock.c_str());
@@ -433,7 +459,8 @@ static int server_main(const std::string& sock) {
   }
   {   // connections still queued get no answer: their clients prove in-process
     std::lock_guard<std::mutex> lk(qm);
-    for (int c : queue) close(c);
+    for (int c : queue)
+      if (c >= 0) close(c);
     queue.clear();
   }
   for (auto& t : pool) t.join();
