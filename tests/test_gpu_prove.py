@@ -258,6 +258,57 @@ def test_wrong_witness_length_code(ctx, zk):
         key.close()
 
 
+def test_witness_from_a_file_equals_witness_from_a_buffer(zk, tmp_path):
+    """zkpoa_groth16_prover_files (the executable's entry point: the .wtns is walked and read through its file descriptor,
+    never mapped) against groth16_prover_zkey_file (rapidsnark's shape: a buffer): same proof bytes for a good witness --
+    also with the two sections in the other order and an unknown third section, which the container allows -- and the same
+    error text for a malformed one (bad magic, truncated section table, truncated values, wrong value count, another
+    field, wrong length for the circuit)."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    zp = tmp_path / "circuit_final.zkey"
+    zp.write_bytes(g["circuit.zkey"])
+    _, w = g16.read_wtns(g["witness.wtns"])
+    sec1 = struct.pack("<I", 32) + le(bn.R) + struct.pack("<I", len(w))
+    sec2 = b"".join(le(x) for x in w)
+    good = {
+        "as written": g["witness.wtns"],
+        "values before header, extra section": g16.write_binfile("wtns", 2, [(7, b"\x01\x02\x03"), (2, sec2), (1, sec1)]),
+    }
+    bad = {
+        "bad magic": b"wtnz" + g["witness.wtns"][4:],
+        "truncated table": g["witness.wtns"][:20],
+        "truncated values": g["witness.wtns"][:-5],
+        "count mismatch": g16.write_binfile("wtns", 2, [(1, sec1[:36] + struct.pack("<I", len(w) + 1)), (2, sec2)]),
+        "other field": g16.write_binfile("wtns", 2, [(1, struct.pack("<I", 32) + le(bn.Q) + struct.pack("<I", len(w))), (2, sec2)]),
+        "short for the circuit": g16.write_wtns(w[:-3]),
+        "no values": g16.write_binfile("wtns", 2, [(1, sec1)]),
+    }
+    os.environ["ZKPOA_R"], os.environ["ZKPOA_S"] = rs["r"], rs["s"]
+    try:
+        for name, img in good.items():
+            wp = tmp_path / "w.wtns"
+            wp.write_bytes(img)
+            zk.groth16_prove(str(zp), str(wp), str(tmp_path / "a.json"), str(tmp_path / "ap.json"))
+            zk.groth16_prove_files(str(zp), str(wp), str(tmp_path / "b.json"), str(tmp_path / "bp.json"))
+            assert (tmp_path / "a.json").read_text() == (tmp_path / "b.json").read_text() == g["proof_rapidsnark.json"], name
+            assert (tmp_path / "ap.json").read_text() == (tmp_path / "bp.json").read_text() == g["public_rapidsnark.json"], name
+        for name, img in bad.items():
+            wp = tmp_path / "w.wtns"
+            wp.write_bytes(img)
+            msgs = []
+            for fn in (zk.groth16_prove, zk.groth16_prove_files):
+                with pytest.raises(zk.ZkpoaError) as ei:
+                    fn(str(zp), str(wp), str(tmp_path / "x.json"), str(tmp_path / "xp.json"))
+                msgs.append(str(ei.value).split(": ", 1)[1])
+            assert msgs[0] == msgs[1], (name, msgs)
+            assert not (tmp_path / "x.json").exists()
+        with pytest.raises(zk.ZkpoaError, match="cannot read witness file"):
+            zk.groth16_prove_files(str(zp), str(tmp_path / "missing.wtns"), str(tmp_path / "x.json"), str(tmp_path / "xp.json"))
+    finally:
+        del os.environ["ZKPOA_R"], os.environ["ZKPOA_S"]
+
+
 def test_bad_zkeys_rejected(ctx, zk):
     g = golden_case("n8")
     z = g["circuit.zkey"]

@@ -126,7 +126,7 @@ def one_shape(z, spec, args):
                     while time.perf_counter() - t0 < 60:
                         time.sleep(0.25)
                         try:
-                            if "complete)" in open(sock + ".log").read():
+                            if "warm-up proof" in open(sock + ".log").read():
                                 break
                         except OSError:
                             pass

@@ -210,6 +210,7 @@ struct zkpoa_zkey {
   // incremental build (zkey_precompute_step: one table per call, from the resident prover's idle time)
   uint64_t table_budget = 0;  // fixed at the first step (half of the HBM free then)
   bool tables_settled = false;   // every table that is wanted and fits has been built (or an attempt failed)
+  bool warmed = false;           // a throw-away proof has run since the tables settled (the lanes' workspaces regrown)
   // digit density of the last witness measured on this handle (msm_density: non-zero digits per scalar for every
   // window width). A circuit's witnesses all look alike (bits stay bits), so it is measured by the first proof only
   // and sizes the windows of later proofs and of the witness tables (zkey_precompute after a proof).
@@ -225,6 +226,7 @@ struct zkpoa_zkey {
     tH_cyclic = false;
     table_budget = 0;
     tables_settled = false;
+    warmed = false;
   }
   void set_full() {
     wlo = 0; wcnt = nVars; clo = 0; ccnt = (uint64_t)nVars - nPublic - 1; hlo = 0; hcnt = domain;
@@ -2684,9 +2686,25 @@ extern "C" int zkpoa_idle_work(void) {
     CachedKey* pick = nullptr;
     for (auto& c : g_key_cache)
       if (c.zk->proofs_done.load() >= 1 && !c.zk->tables_settled && (!pick || c.last_use > pick->last_use)) pick = &c;
-    if (!pick) return 0;
     zkpoa_context* ctx = ds->ctx[0];
     ZK_HIP(hipSetDevice(ctx->dev.device));
+    if (!pick) {
+      // Tables complete: one throw-away proof on the witness the key still holds. Building the tables gave the lanes'
+      // workspaces back to the allocator, and the first proof through the tables would otherwise pay for regrowing them
+      // (0.5-0.6 s at the layer-two / -three shapes) inside a request.
+      for (auto& c : g_key_cache)
+        if (c.zk->tables_settled && c.zk->table_bytes && !c.zk->warmed && c.zk->d_witness && is_full_key(c.zk)) {
+          auto t0 = std::chrono::steady_clock::now();
+          c.zk->warmed = true;
+          uint8_t parts[384];
+          prove_partials(ctx, c.zk, parts);
+          if (verbose)
+            fprintf(stderr, "zkpoa: idle: warm-up proof through the new tables: %.0f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+          return 1;
+        }
+      return 0;
+    }
     const uint64_t before = pick->zk->table_bytes;
     auto t0 = std::chrono::steady_clock::now();
     try {
