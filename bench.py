@@ -65,7 +65,7 @@ def pmc_traffic(workload, kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated on this access pattern:
     profiles/rNN_pmc_hbm_traffic.json, newest round first). None when this workload has not been profiled."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % rnd)
         try:
             with open(path) as f:

@@ -2,11 +2,12 @@
 usage: python tools/build_profile_summary.py [round, default r02]"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", "profiles_" + RND)
 DST = os.path.join(ROOT, "profiles")
-for old in glob.glob(os.path.join(DST, RND + "_*")):
-    os.remove(old)
+for pat in ("_bench_*", "_kernel_stats_*", "_pmc_hbm_traffic.json", "_timeline_*"):   # only what this script writes
+    for old in glob.glob(os.path.join(DST, RND + pat)):
+        os.remove(old)
 
 def only(pattern):
     """exactly one match: gpurun merges into an existing gpurun_out/, so stale runs must be deleted first"""
