@@ -259,3 +259,28 @@ def test_malformed_device_environment_is_an_input_error(zk, tmp_path):
             assert var in rc.stderr, rc.stderr
         else:
             assert "no HIP device" in rc.stderr or var in rc.stderr
+
+
+def test_server_pool_answers_concurrent_requests_without_gpu(zk, tmp_path):
+    """The resident prover serves from a pool of threads (r04). Sixteen clients at once, each with its own missing witness
+    (an INPUT error, answered before any GPU work, so the server stays up on this box): every client gets its own message
+    and exit code 1, nothing is written, and the server still stops on request. (The same sixteen under ThreadSanitizer
+    -- the `prover` executable is host-only code: g++ -fsanitize=thread -- report nothing)"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_prove.py::test_server_overlaps_requests_without_mixing_them_up")
+    g = golden_case("n8")
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    env = dict(os.environ, ZKPOA_SERVER=str(tmp_path / "p.sock"), ZKPOA_SERVER_IDLE_S="30", ZKPOA_SERVER_WORKERS="4")
+    try:
+        procs = [subprocess.Popen([zk.PROVER_BIN, "c.zkey", "missing%d.wtns" % i, "p%d.json" % i, "u%d.json" % i], env=env,
+                                  cwd=tmp_path, stderr=subprocess.PIPE, text=True) for i in range(16)]
+        for i, pr in enumerate(procs):
+            _, err = pr.communicate(timeout=120)
+            assert pr.returncode == 1 and ("missing%d.wtns" % i) in err and "cannot read witness file" in err, err
+            assert not (tmp_path / ("p%d.json" % i)).exists()
+        assert os.path.exists(tmp_path / "p.sock")
+    finally:
+        rc = subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+    assert rc.returncode == 0
