@@ -191,28 +191,10 @@ struct DeviceCtx {
         const bool flat = pe && !strcmp(pe, "flat"), none = pe && !strcmp(pe, "none"), ladder2 = pe && !strcmp(pe, "ladder2");
         const bool top1 = pe && !strcmp(pe, "top1");   // the chain's lane alone at the top level
         static const int kLadder[6] = {2, 2, 1, 1, 0, 0}, kLadder2[6] = {2, 0, 1, 2, 0, 1}, kTop1[6] = {2, 1, 1, 0, 0, 0};
-        // the lanes come up side by side (a stream + its pinned buffer + events is ~12 ms each, and a one-shot layer-one
-        // proof waits for them: ZKPOA_LANES_SERIAL=1 creates them one after the other, as r03 did)
-        auto level = [&](int i) { return none ? 0 : ladder2 ? kLadder2[i] : top1 ? kTop1[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]; };
-        const char* ser = getenv("ZKPOA_LANES_SERIAL");
-        if (ser && *ser == '1') {
-          for (int i = 1; i < kEagerLanes; i++) lanes[i].init(level(i));
-        } else {
-          std::exception_ptr errs[kEagerLanes];
-          std::vector<std::thread> th;
-          for (int i = 1; i < kEagerLanes; i++)
-            th.emplace_back([&, i] {
-              try {
-                ZK_HIP(hipSetDevice(device));
-                lanes[i].init(level(i));
-              } catch (...) {
-                errs[i] = std::current_exception();
-              }
-            });
-          for (auto& t : th) t.join();
-          for (int i = 1; i < kEagerLanes; i++)
-            if (errs[i]) std::rethrow_exception(errs[i]);
-        }
+        // (created one after the other: side by side they take just as long -- the runtime serialises stream creation;
+        // measured r04, "lanes up" 47-58 ms either way)
+        for (int i = 1; i < kEagerLanes; i++)
+          lanes[i].init(none ? 0 : ladder2 ? kLadder2[i] : top1 ? kTop1[i] : flat ? (i == 3 ? 1 : 0) : kLadder[i]);
       } catch (...) {
         bg_err_ = std::current_exception();
         {
