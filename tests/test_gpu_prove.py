@@ -500,6 +500,33 @@ def test_prover_cli_over_distinct_gpus(zk, tmp_path):
         assert (tmp_path / "mid.json").read_text() == zk.proof_to_json(want_pts, "rapidsnark")
 
 
+def test_a_stale_exchange_is_caught_by_the_self_check_and_repeated_with_copies(zk, tmp_path):
+    """The peer-store exchanges of the multi-GPU drop-in rest on a memory-visibility rule no multi-GPU node has confirmed
+    yet. Safety net: the first three proofs of a key are verified against the zkey's own verification key, and a proof
+    that fails is repeated with hipMemcpyPeerAsync exchanges, which then stay on. Here rank 0 withholds its first push
+    in the FIRST proof of the process (test hook: its peers read whatever their fresh receive buffers hold, as a missing
+    release / acquire would leave them): all three calls must still write the golden proof, the first with a warning."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "circuit_final.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "witness.wtns").write_bytes(g["witness.wtns"])
+    sock = str(tmp_path / "prover.sock")
+    env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_SERVER=sock, ZKPOA_SERVER_IDLE_S="60",
+               ZKPOA_DEVICES="0,0,0,0", ZKPOA_TEST_STALE_EXCHANGE="1", ZKPOA_VERBOSE="1")
+    argv = [zk.PROVER_BIN, "circuit_final.zkey", "witness.wtns", "proof.json", "public.json"]
+    try:
+        for i in range(3):
+            if os.path.exists(tmp_path / "proof.json"):
+                os.remove(tmp_path / "proof.json")
+            rc = subprocess.run(argv, env=env, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+            assert rc.returncode == 0, rc.stderr
+            assert (tmp_path / "proof.json").read_text() == g["proof_rapidsnark.json"], i
+        log = (tmp_path / "prover.sock.log").read_text()
+        assert log.count("failed its self-check with the peer-store exchanges") == 1
+    finally:
+        subprocess.run([zk.PROVER_BIN, "--stop-server"], env=env, cwd=tmp_path, timeout=60)
+
+
 @pytest.mark.parametrize("fail", ["2:1", "0:2", "3:3"])
 def test_a_failing_rank_ends_the_multi_rank_proof_with_an_error_not_a_hang(zk, tmp_path, fail):
     """One rank of a four-rank proof fails (test hook) before the first barrier, between the two exchanges or before its

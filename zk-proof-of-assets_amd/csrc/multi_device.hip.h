@@ -371,11 +371,27 @@ MultiKey* multi_key_load(DeviceSet* ds, const uint8_t* buf, uint64_t size) {
 
 // One exchange of the split chain, rank g's half: push chunk h of `src` (what rank h needs from g) into slot g of rank
 // h's receive buffer, all on g's lane-0 stream behind the stage that produced `src`; then mark the stream.
-inline bool multi_force_copies() {   // ZKPOA_EXCHANGE=copy: hipMemcpyPeerAsync exchanges, whole witness per rank
-  static const bool v = [] {
+// ZKPOA_EXCHANGE=copy: hipMemcpyPeerAsync exchanges, whole witness per rank -- also switched on for the rest of the
+// process when a proof made with the peer-store exchanges fails its self-check (multi_prove_to_json)
+inline std::atomic<int>& multi_copies_state() {
+  static std::atomic<int> v{[] {
     const char* e = getenv("ZKPOA_EXCHANGE");
-    return e && !strcmp(e, "copy");
+    return e && !strcmp(e, "copy") ? 1 : 0;
+  }()};
+  return v;
+}
+inline bool multi_force_copies() { return multi_copies_state().load() != 0; }
+// tests: ZKPOA_TEST_STALE_EXCHANGE=<n> -- in the n-th multi-rank proof of the process rank 0 does not push its first
+// exchange (its peers keep what the previous proof left there): what a missing release / acquire would look like
+inline long multi_test_stale_at() {
+  static const long v = [] {
+    const char* e = getenv("ZKPOA_TEST_STALE_EXCHANGE");
+    return e && *e ? strtol(e, nullptr, 10) : 0L;
   }();
+  return v;
+}
+inline std::atomic<long>& multi_proof_counter() {
+  static std::atomic<long> v{0};
   return v;
 }
 
@@ -384,6 +400,10 @@ void multi_push(DeviceSet* ds, MultiKey* mk, size_t g, const void* src, std::vec
   const uint64_t chunk = mk->xbytes / G;
   hipStream_t st = ds->ctx[g]->dev.lanes[0].stream;
   if (ds->peer_ok && !multi_force_copies() && chunk % 16 == 0) {
+    if (g == 0 && &dst == &mk->xb1 && multi_test_stale_at() && multi_proof_counter().load() == multi_test_stale_at()) {
+      ZK_HIP(hipEventRecord(done, st));   // (test hook: this push is withheld)
+      return;
+    }
     // one kernel writes all G chunks into the peers' receive buffers: all links busy at once (abc.hip.h)
     XchgDst d;
     for (size_t h = 0; h < 8; h++) d.p[h] = h < G ? reinterpret_cast<char*>(dst[h]) + g * chunk : nullptr;
@@ -569,13 +589,31 @@ int multi_prove_to_json(DeviceSet* ds, MultiKey* mk, const WtnsSrc& wsrc, char* 
   const uint8_t *rp = nullptr, *sp = nullptr;
   env_blinding(rb, sb, rp, sp);
   auto t0 = std::chrono::steady_clock::now();
+  multi_proof_counter()++;
+  const bool kernel_exchange = ds->ids.size() > 1 && ds->peer_ok && !multi_force_copies();
   multi_prove_partials(ds, mk, w, parts);
   zkey_header_bytes(z0, header);
   prove_assemble(header, parts, rp, sp, pts);
   c0->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::vector<uint8_t> pub_store;
   const uint8_t* pubs = w.publics(z0->nPublic, pub_store);
-  selfcheck(c0, z0, pts, pubs);
+  // The peer-store exchanges rest on a memory-visibility rule that no run on a multi-GPU node has confirmed yet (DESIGN
+  // section 6), so the pairing check that normally guards a key's first proof guards its first three here -- a stale
+  // receive buffer can only show from the second proof on -- and a proof that fails it is not an error yet: it is
+  // repeated with hipMemcpyPeerAsync exchanges (DMA, ordered by the runtime), which then stay on for this process.
+  try {
+    selfcheck(c0, z0, pts, pubs, kernel_exchange ? 3 : 1);
+  } catch (const SelfCheckFailed&) {
+    if (!kernel_exchange) throw;
+    multi_copies_state().store(1);
+    fprintf(stderr, "zkpoa: WARNING: a proof over %zu ranks failed its self-check with the peer-store exchanges; repeating it "
+                    "with hipMemcpyPeerAsync exchanges, which stay on for the rest of this process (ZKPOA_EXCHANGE=copy makes "
+                    "them the default; DESIGN.md section 6 names the suspects)\n", ds->ids.size());
+    multi_prove_partials(ds, mk, w, parts);
+    prove_assemble(header, parts, rp, sp, pts);
+    c0->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    selfcheck(c0, z0, pts, pubs, ~0ull);   // this one must verify
+  }
   if (req_getenv("ZKPOA_VERBOSE"))
     fprintf(stderr, "zkpoa: one proof over %zu ranks: H-scalar chain %s, sections 5-8 %s, %.2f GB of fixed-base tables; "
                     "prove %.2f ms\n", ds->ids.size(), mk->split ? "split (2 peer-to-peer exchanges)" : "replicated",

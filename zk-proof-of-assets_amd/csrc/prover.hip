@@ -1201,10 +1201,17 @@ int selfcheck_mode() {
   return 1;
 }
 
-void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_points[256], const uint8_t* public_le) {
+struct SelfCheckFailed : ProverError {   // the proof was computed and does not verify (as opposed to "could not be checked")
+  explicit SelfCheckFailed(const std::string& s) : ProverError(PROVER_ERROR, s) {}
+};
+
+// first_n: in the default mode the first that many proofs of a key are checked (1; the multi-GPU path checks 3: a stale
+// exchange buffer can only show from the second proof on)
+void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_points[256], const uint8_t* public_le,
+               uint64_t first_n = 1) {
   ctx->ms[6] = 0;
   const int mode = selfcheck_mode();
-  if (mode == 0 || zk->vkey_points.empty() || (mode == 1 && zk->selfchecks_done)) return;
+  if (mode == 0 || zk->vkey_points.empty() || (mode == 1 && zk->selfchecks_done >= first_n)) return;
   auto t0 = std::chrono::steady_clock::now();
   char msg[256] = {0};
   int rc = zkpoa_groth16_verify_points(zk->vkey_points.data(), (unsigned long)zk->vkey_points.size(), proof_points,
@@ -1216,7 +1223,7 @@ void selfcheck(zkpoa_context* ctx, const zkpoa_zkey* zk, const uint8_t proof_poi
     return;
   }
   if (rc == ZKPOA_VERIFY_INVALID_PROOF)
-    throw ProverError(PROVER_ERROR,
+    throw SelfCheckFailed(
                       "self-check failed: the proof does not verify against the verification key inside the zkey "
                       "(sections 2-3). Either the witness does not satisfy the circuit, or this zkey does not follow the "
                       "conventions the prover assumes: section 4 coefficients stored as coef*R^2 mod r; section 9 H points = "
