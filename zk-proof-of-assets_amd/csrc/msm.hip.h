@@ -915,7 +915,7 @@ inline size_t msm_sort_workspace_bytes(const MsmPlan& p) {
   size_t bytes = 0;
   bytes += al256((size_t)p.TB * 4);                  // counts
   bytes += al256(((size_t)p.TB + 1) * 4) * 2;        // off0, po_a
-  bytes += al256(T * 4) * 2;                         // digits, sorted
+  bytes += al256(T * 4) + al256(T * 8);              // sorted; digits (T words) or the compact entry list (T pairs)
   if (sp.npass > 1) bytes += al256(T * 8);           // entries between passes (ping)
   if (sp.npass > 2) bytes += al256(T * 8);           // (pong)
   for (uint32_t l = 0; l < sp.npass; l++) {
@@ -990,7 +990,17 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
   const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_lo);
   sr.off0 = ws.take<uint32_t>(p.TB + 1);
   sr.po_a = ws.take<uint32_t>(p.TB + 1);
-  uint32_t* digits = ws.take<uint32_t>(T_max);
+  // sparse scalars in the fixed-base form (a witness through its tables): a compact entry list instead of the dense
+  // digit array (msm_sort.hip.h msm_entries_kernel); ZKPOA_NO_SPARSE=1 keeps the dense form (measurement)
+  static const bool no_sparse = [] {
+    const char* e = getenv("ZKPOA_NO_SPARSE");
+    return e && *e == '1';
+  }();
+  const double* dens = msm_density_hint();
+  const bool sparse = merged && p.n && dens && dens[p.c] < 0.6 * (double)p.W && !no_sparse;
+  uint32_t* digits = sparse ? nullptr : ws.take<uint32_t>(T_max);
+  uint2* elist = sparse ? ws.take<uint2>(T_max) : nullptr;
+  uint32_t* pre = sparse ? ws.take<uint32_t>(8) : nullptr;   // [0..1] offsets, [4..5] task offsets of pass 0's one segment
   uint2* ebuf[2] = {sp.npass > 1 ? ws.take<uint2>(T_max) : nullptr, sp.npass > 2 ? ws.take<uint2>(T_max) : nullptr};
   // per pass: output segment counts / offsets / task offsets (the last pass writes the bucket arrays) and bases
   uint32_t *seg_off[kSortMaxPasses] = {}, *seg_tpo[kSortMaxPasses] = {}, *base[kSortMaxPasses] = {};
@@ -1009,13 +1019,19 @@ inline MsmSorted msm_sort_phase(Lane& lane, const void* d_scalars, size_t n, int
 
   ZK_HIP(hipMemsetAsync(zero_lo, 0, zero_bytes, st));
   const uint32_t nblk = (p.n + 255) / 256;
-  if (p.n) hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
+  if (p.n && !sparse) hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, d_scalars, p.n, p.c, p.W, digits);
+  if (sparse) {
+    const uint32_t per_wg = kEntriesThreads * kEntriesPerThread;
+    hipLaunchKernelGGL(msm_entries_kernel, dim3((p.n + per_wg - 1) / per_wg), dim3(kEntriesThreads), 0, st, d_scalars, p.n,
+                       p.c, p.W, elist, misc + 8);
+    hipLaunchKernelGGL(msm_entries_finish_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)(misc + 8), sp.CH, pre, pre + 4);
+  }
   for (uint32_t l = 0; l < sp.npass; l++) {
-    const bool first = l == 0, last = l + 1 == sp.npass;
-    const uint2* in = first ? nullptr : ebuf[(l - 1) & 1];
+    const bool first = l == 0 && !sparse, last = l + 1 == sp.npass;
+    const uint2* in = l == 0 ? (const uint2*)elist : ebuf[(l - 1) & 1];
     uint2* out = last ? nullptr : ebuf[l & 1];
-    const uint32_t* in_off = first ? nullptr : seg_off[l - 1];
-    const uint32_t* tpo = first ? nullptr : seg_tpo[l - 1];
+    const uint32_t* in_off = l == 0 ? (const uint32_t*)pre : seg_off[l - 1];
+    const uint32_t* tpo = l == 0 ? (const uint32_t*)(pre ? pre + 4 : nullptr) : seg_tpo[l - 1];
     uint32_t* out_cnt = last ? sr.counts : seg_cnt[l];
     uint32_t* out_off = last ? sr.off0 : seg_off[l];
     const dim3 grid = first ? dim3(sp.chunks0, sp.W) : dim3((uint32_t)sp.tasks_max[l]);

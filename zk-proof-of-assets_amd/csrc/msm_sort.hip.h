@@ -109,6 +109,100 @@ static __global__ __launch_bounds__(256) void msm_digits_kernel(const void* __re
   }
 }
 
+// ---- K0', sparse scalars, fixed-base form -----------------------------------------------------------------
+// A witness is mostly bits and short limbs: at the c = 17 of a witness table a scalar has ~3 non-zero digits of 15, and
+// the dense digit array above (n x W words written once, read by pass 0's count and again by its scatter) is four
+// fifths zeros. When the digit density says so (msm_sort_phase), the digits go straight into a COMPACT entry list
+// instead -- (table index w * n + i | sign << 31, |digit| - 1), 8 bytes per non-zero digit, in no particular order (a
+// bucket sum does not care) -- and pass 0 runs over that list exactly as the later passes run over theirs. One
+// block-wide scan + one global atomic per block reserve the block's range of the list.
+constexpr uint32_t kEntriesThreads = 1024, kEntriesPerThread = 2;          // 2048 scalars per workgroup
+constexpr uint32_t kEntriesStage = 8192;                                    // entries a workgroup stages in LDS (64 KiB)
+// signed c-bit digits of one sign-normalised scalar, lowest window first: f(w, magnitude, sign) for every non-zero one
+template <class Fn>
+ZK_DEV void for_nonzero_digits(uint32_t (&s)[8], bool neg, uint32_t c, uint32_t W, Fn f) {
+  const uint32_t Nb = 1u << (c - 1), mask = (1u << c) - 1u;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    const uint32_t d = (s[0] & mask) + carry;
+    scalar_shr(s, c);
+    carry = d > Nb ? 1u : 0u;
+    const uint32_t mag = carry ? (mask + 1u - d) : d;
+    if (mag) f(w, mag, (carry != 0) != neg);
+  }
+}
+// One global atomic per WORKGROUP reserves its range of the list, so the workgroups are large: with 256-scalar
+// workgroups the 70 k atomics of an 18 M-scalar query on one counter were the whole kernel (0.89 ms for 0.35 ms of bytes).
+static __global__ __launch_bounds__(kEntriesThreads) void msm_entries_kernel(const void* __restrict__ scalars, uint32_t n,
+                                                                            uint32_t c, uint32_t W, uint2* __restrict__ out,
+                                                                            uint32_t* __restrict__ counter) {
+  __shared__ uint32_t wave_tot[kEntriesThreads / 64];
+  __shared__ uint32_t s_base, s_total;
+  __shared__ uint2 stage[kEntriesStage];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t sc[kEntriesPerThread][8];
+  bool neg[kEntriesPerThread];
+  uint32_t idx[kEntriesPerThread], k = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kEntriesPerThread; q++) {
+    idx[q] = (blockIdx.x * kEntriesPerThread + q) * kEntriesThreads + tid;
+    neg[q] = false;
+    if (idx[q] < n) {
+      load_scalar(scalars, idx[q], sc[q]);
+      neg[q] = scalar_normalize(sc[q]);
+      uint32_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = sc[q][j];
+      for_nonzero_digits(t, neg[q], c, W, [&](uint32_t, uint32_t, bool) { k++; });
+    }
+  }
+  // exclusive scan of k over the workgroup
+  uint32_t x = k;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) wave_tot[wave] = x;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t v = 0; v < kEntriesThreads / 64; v++) {
+    const uint32_t t = wave_tot[v];
+    if (v < wave) before += t;
+    total += t;
+  }
+  uint32_t at = before + x - k;
+  if (tid == 0) {
+    s_total = total;
+    s_base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  const bool staged = s_total <= kEntriesStage;
+  const uint32_t base = s_base;
+#pragma unroll
+  for (uint32_t q = 0; q < kEntriesPerThread; q++)
+    if (idx[q] < n)
+      for_nonzero_digits(sc[q], neg[q], c, W, [&](uint32_t w, uint32_t mag, bool sign) {
+        const uint2 e = make_uint2((w * n + idx[q]) | (sign ? 0x80000000u : 0u), mag - 1u);
+        if (staged) stage[at] = e;
+        else out[base + at] = e;
+        at++;
+      });
+  if (staged) {
+    __syncthreads();
+    for (uint32_t e = tid; e < s_total; e += kEntriesThreads) out[base + e] = stage[e];
+  }
+}
+// the list as pass 0's one input segment: offsets {0, T}, task offsets {0, ceil(T / CH)}
+static __global__ void msm_entries_finish_kernel(const uint32_t* __restrict__ counter, uint32_t CH, uint32_t* __restrict__ off,
+                                                 uint32_t* __restrict__ tpo) {
+  const uint32_t T = *counter;
+  off[0] = 0;
+  off[1] = T;
+  tpo[0] = 0;
+  tpo[1] = (T + CH - 1u) / CH;
+}
+
 // ---- one pass ------------------------------------------------------------------------------------------
 // Task geometry. FIRST: task = (chunk blockIdx.x, window blockIdx.y) of the digit array; otherwise task
 // t = blockIdx.x over the segments of `in_off` with task offsets `tpo`. Returns false when the block has no task.
