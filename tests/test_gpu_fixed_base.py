@@ -138,3 +138,48 @@ def test_prove_with_partial_tables_and_shards(ctx, zk):
         assert circ.prove(r_, s_)[0] == want              # whole key again: tables back in use
     finally:
         circ.close()
+
+
+@pytest.mark.parametrize("pattern", ["w0_only", "all_ones", "plus_minus_one", "limbs64", "mixed"])
+def test_sparse_first_pass_extreme_witnesses(ctx, zk, pattern):
+    """The witness MSMs through tables take a compact entry list instead of the dense digit array when the witness is
+    sparse in digits (csrc/msm_sort.hip.h msm_entries_kernel). Witnesses at the edges of that path -- nothing but w[0],
+    all ones (one hot bucket holds everything), alternating 1 / r - 1 (every digit negative or positive one), 64-bit
+    limbs, and a mix with full-width values -- must give the proof the classic (dense, table-free) form gives, and that
+    proof must match the known discrete logs with H scalars the C oracle confirms."""
+    import torch
+    from zkpoa_amd.synthetic import SyntheticCircuit
+    k, m = 12, 3000
+    circ = SyntheticCircuit(zk, ctx, k, m, n_public=2, seed=5, witness_like=True)
+    try:
+        w = np.zeros((m, 4), dtype=np.uint64)
+        rl = [(R >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+        if pattern == "all_ones":
+            w[:, 0] = 1
+        elif pattern == "plus_minus_one":
+            w[:, 0] = 1
+            w[1::2] = [rl[0] - 1, rl[1], rl[2], rl[3]]                 # r - 1
+        elif pattern == "limbs64":
+            w[:, 0] = np.random.default_rng(3).integers(1, 1 << 63, size=m, dtype=np.uint64) * 2 + 1
+        elif pattern == "mixed":
+            g = np.random.default_rng(4)
+            w[:, 0] = g.integers(0, 2, size=m, dtype=np.uint64)
+            full = g.integers(0, 1 << 62, size=(m // 50 + 1, 4), dtype=np.uint64)
+            full[:, 3] &= np.uint64((1 << 60) - 1)                     # < 2^252 < r: canonical field elements
+            w[::50] = full[: len(w[::50])]
+        w[0] = (1, 0, 0, 0)
+        circ.w_limbs = w
+        circ.d_witness = torch.from_numpy(w.view(np.uint8).reshape(-1).copy()).cuda()
+        r_, s_ = 11, 22
+        want, _ = circ.prove(r_, s_)                                    # no tables: classic form, dense digits
+        P = circ.h_scalars()
+        assert P.tobytes() == co.h_scalars(circ.coeff_section_bytes(), circ.witness_bytes(), m, k)
+        a, b, c = circ.expected_dlogs(r_, s_, P)
+        assert g16.g1_from_bytes(want, 0) == bn.g1_mul(bn.G1_GEN, a)
+        assert g16.g2_from_bytes(want, 64) == bn.g2_mul(bn.G2_GEN, b)
+        assert g16.g1_from_bytes(want, 192) == bn.g1_mul(bn.G1_GEN, c)
+        assert circ.key.precompute() > 0                                 # tables sized with this witness's digit density
+        for _ in range(2):
+            assert circ.prove(r_, s_)[0] == want
+    finally:
+        circ.close()
