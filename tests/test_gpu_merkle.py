@@ -173,3 +173,52 @@ def test_merkle_tree_cli_drop_in(zk, tmp_path):
     rc = subprocess.run([zk.MERKLE_BIN, "-a", str(bad), "-p", str(tmp_path / "parsed_sigs.json"), "-o", str(out)],
                         capture_output=True, text=True, timeout=120)
     assert rc.returncode != 0 and "not below the BN254 scalar modulus" in rc.stderr
+
+
+@pytest.mark.parametrize("threads", ["1", "7"])
+def test_merkle_tree_cli_reads_a_messy_csv_in_parallel(zk, tmp_path, threads):
+    """The CLI maps the anonymity set and parses it in pieces cut at line starts, one per thread (a 10 M-line set is ~650 MB
+    of text). 5000 rows with everything the line-at-a-time reader accepted -- blank lines, CRLF endings, quoted fields,
+    padding blanks, a last line without a newline -- read on 1 and on 7 threads must give the root the C oracle computes
+    from the same rows; a malformed row in the middle is reported with its text."""
+    rng = random.Random(99)
+    rows = [(rng.randrange(1 << 160), rng.randrange(1 << 90)) for _ in range(5000)]
+    lines = ["address,eth_balance"]
+    for i, (a, b) in enumerate(rows):
+        s = ("0x%040x" % a, str(b))
+        form = i % 5
+        line = {0: "%s,%s", 1: '"%s","%s"', 2: "  %s , %s  ", 3: "%s,%s\r", 4: "0X%s,%s"}[form] % (
+            (s[0][2:], s[1]) if form == 4 else s)
+        lines.append(line)
+        if i % 97 == 0:
+            lines.append("")                                           # blank lines are skipped
+    text = "\n\n" + "\n".join(lines)                                   # leading blank lines, no final newline
+    (tmp_path / "set.csv").write_text(text, newline="")
+    own = [17, 2048, 4999]
+    poa = {"accountAttestations": [{"accountData": {"address": {"__bigint__": str(rows[i][0])},
+                                                       "balance": {"__bigint__": str(rows[i][1])}}} for i in own]}
+    (tmp_path / "poa.json").write_text(json.dumps(poa))
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, ZKPOA_MERKLE_THREADS=threads)
+    argv = [zk.MERKLE_BIN, "-a", str(tmp_path / "set.csv"), "-p", str(tmp_path / "poa.json"), "-o", str(out)]
+    rc = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=120)
+    assert rc.returncode == 0, rc.stderr
+    assert "Done creating 5000 leaves" in rc.stdout
+    want = co.merkle_levels(b"".join(le(a) for a, _ in rows), b"".join(le(b) for _, b in rows), 13, 8)
+    root = int.from_bytes(want[-32:], "little")
+    assert (out / "merkle_root.json").read_text() == '{\n  "__bigint__": "%d"\n}' % root
+    proofs = json.loads((out / "merkle_proofs.json").read_text())
+    assert [int(l["address"]["__bigint__"]) for l in proofs["leaves"]] == [rows[i][0] for i in own]
+    # fold every path with the oracle's hash
+    for k, i in enumerate(own):
+        node = int(proofs["leaves"][k]["hash"]["__bigint__"])
+        assert node == P.poseidon([rows[i][0], rows[i][1]])
+        for e, bit in zip(proofs["path_elements"][k], proofs["path_indices"][k]):
+            e = int(e["__bigint__"])
+            node = P.poseidon([e, node] if bit else [node, e])
+        assert node == root
+    bad = text.replace("0x%040x" % rows[3000][0], "0x%039xg" % (rows[3000][0] >> 4), 1)
+    (tmp_path / "set.csv").write_text(bad, newline="")
+    rc = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=120)
+    assert rc.returncode == 1 and "malformed address" in rc.stderr and ("%039xg" % (rows[3000][0] >> 4)) in rc.stderr

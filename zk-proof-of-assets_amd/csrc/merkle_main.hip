@@ -15,10 +15,17 @@
 #include <unistd.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+#include <exception>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 using zkpoa::json::JVal;
@@ -60,20 +67,25 @@ struct U256 {
   }
 };
 
-static U256 parse_num(const std::string& s, unsigned base, const char* what) {
+static U256 parse_num(const char* b, const char* e, unsigned base, const char* what) {
   U256 x;
-  if (s.empty()) throw std::runtime_error(std::string("empty ") + what);
-  for (char ch : s) {
+  if (b == e) throw std::runtime_error(std::string("empty ") + what);
+  for (const char* q = b; q < e; q++) {
+    const char ch = *q;
     unsigned d;
     if (ch >= '0' && ch <= '9') d = (unsigned)(ch - '0');
     else if (base == 16 && ch >= 'a' && ch <= 'f') d = (unsigned)(ch - 'a' + 10);
     else if (base == 16 && ch >= 'A' && ch <= 'F') d = (unsigned)(ch - 'A' + 10);
-    else throw std::runtime_error(std::string("malformed ") + what + ": " + s);
-    if (!x.mul_add(base, d)) throw std::runtime_error(std::string(what) + " does not fit 256 bits: " + s);
+    else throw std::runtime_error(std::string("malformed ") + what + ": " + std::string(b, e));
+    if (!x.mul_add(base, d)) throw std::runtime_error(std::string(what) + " does not fit 256 bits: " + std::string(b, e));
   }
   // light-poseidon's hash_bytes_be refuses inputs that are not field elements (the Rust binary would panic)
-  if (!x.below_r()) throw std::runtime_error(std::string(what) + " is not below the BN254 scalar modulus: " + s);
+  if (!x.below_r()) throw std::runtime_error(std::string(what) + " is not below the BN254 scalar modulus: " + std::string(b, e));
   return x;
+}
+
+static U256 parse_num(const std::string& s, unsigned base, const char* what) {
+  return parse_num(s.data(), s.data() + s.size(), base, what);
 }
 
 static std::string trim(const std::string& s) {
@@ -96,12 +108,139 @@ static void write_file(const std::string& path, const std::string& text) {
     throw std::runtime_error("cannot write " + path);
 }
 
+// ---- the anonymity set: a 10 M-line csv is ~650 MB of text, and a line-at-a-time reader would take longer over it than
+// the GPU takes over the whole tree (0.12 s). The file is mapped, cut at line starts into one piece per thread, and every
+// piece is parsed twice: lines counted first (so that each piece knows where its rows go), then converted in place.
+// Same rules as before: blank lines are skipped, the first non-blank line is the heading, fields are trimmed of blanks
+// and double quotes, an address is 0x-prefixed hex, a balance decimal, both below the scalar modulus.
+static bool is_trim(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '"'; }
+static void trim_span(const char*& b, const char*& e) {
+  while (b < e && is_trim(*b)) b++;
+  while (e > b && is_trim(e[-1])) e--;
+}
+// calls f(line_begin, line_end) for every non-blank line of [b, e) (e at a line start or the end of the file)
+template <class Fn>
+static void for_lines(const char* b, const char* e, Fn f) {
+  while (b < e) {
+    const char* nl = static_cast<const char*>(memchr(b, '\n', (size_t)(e - b)));
+    const char* le = nl ? nl : e;
+    const char *tb = b, *te = le;
+    trim_span(tb, te);
+    if (tb < te) f(b, le);
+    b = nl ? nl + 1 : e;
+  }
+}
+static void parse_row(const char* b, const char* e, uint64_t* addr, uint64_t* bal) {
+  const char* comma = static_cast<const char*>(memchr(b, ',', (size_t)(e - b)));
+  if (!comma) throw std::runtime_error("Failed to find balance in line in csv file: " + std::string(b, e));
+  const char *ab = b, *ae = comma, *bb = comma + 1, *be = e;
+  trim_span(ab, ae);
+  trim_span(bb, be);
+  if (ae - ab < 3 || ab[0] != '0' || (ab[1] != 'x' && ab[1] != 'X'))
+    throw std::runtime_error("address is not 0x-prefixed hex: " + std::string(ab, ae));
+  const U256 av = parse_num(ab + 2, ae, 16, "address"), bv = parse_num(bb, be, 10, "balance");
+  memcpy(addr, av.v, 32);
+  memcpy(bal, bv.v, 32);
+}
+static void read_anonymity_set(const std::string& path, std::vector<uint64_t>& addr, std::vector<uint64_t>& bal) {
+  int fd = open(path.c_str(), O_RDONLY);
+  struct stat sb;
+  if (fd < 0 || fstat(fd, &sb) != 0) {
+    if (fd >= 0) close(fd);
+    throw std::runtime_error("cannot open " + path);
+  }
+  const size_t size = (size_t)sb.st_size;
+  if (size == 0) {
+    close(fd);
+    return;
+  }
+  void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+  const char* base = static_cast<const char*>(map);
+  const char* end = base + size;
+  try {
+    // the heading: the first non-blank line
+    const char* body = end;
+    {
+      const char* b = base;
+      while (b < end) {
+        const char* nl = static_cast<const char*>(memchr(b, '\n', (size_t)(end - b)));
+        const char* le = nl ? nl : end;
+        const char *tb = b, *te = le;
+        trim_span(tb, te);
+        b = nl ? nl + 1 : end;
+        if (tb < te) {
+          body = b;
+          break;
+        }
+      }
+    }
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 16) T = 16;
+    bool forced = false;
+    if (const char* e = getenv("ZKPOA_MERKLE_THREADS")) {
+      char* rest = nullptr;
+      const long v = strtol(e, &rest, 10);
+      if (rest == e || *rest || v < 1 || v > 256)
+        throw std::runtime_error(std::string("ZKPOA_MERKLE_THREADS must be 1..256, not '") + e + "'");
+      T = (unsigned)v;
+      forced = true;
+    }
+    if (T < 1) T = 1;
+    if ((size_t)(end - body) < (1u << 16) && !forced) T = 1;
+    std::vector<const char*> cut(T + 1, end);
+    cut[0] = body;
+    for (unsigned t = 1; t < T; t++) {   // piece boundaries moved forward to the next line start
+      const char* p = body + (size_t)(end - body) / T * t;
+      if (p < cut[t - 1]) p = cut[t - 1];
+      const char* nl = p < end ? static_cast<const char*>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+      cut[t] = nl ? nl + 1 : end;
+    }
+    std::vector<uint64_t> rows(T, 0);
+    std::vector<std::exception_ptr> errs(T);
+    auto run = [&](auto fn) {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+          try {
+            fn(t);
+          } catch (...) {
+            errs[t] = std::current_exception();
+          }
+        });
+      for (auto& x : th) x.join();
+      for (auto& e : errs)
+        if (e) std::rethrow_exception(e);   // the first failing piece in file order
+    };
+    run([&](unsigned t) { for_lines(cut[t], cut[t + 1], [&](const char*, const char*) { rows[t]++; }); });
+    std::vector<uint64_t> first(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) first[t + 1] = first[t] + rows[t];
+    addr.assign(4 * first[T], 0);
+    bal.assign(4 * first[T], 0);
+    run([&](unsigned t) {
+      uint64_t r = first[t];
+      for_lines(cut[t], cut[t + 1], [&](const char* b, const char* e) {
+        parse_row(b, e, &addr[4 * r], &bal[4 * r]);
+        r++;
+      });
+    });
+  } catch (...) {
+    munmap(map, size);
+    throw;
+  }
+  munmap(map, size);
+}
+
 #define ZK_CALL(expr, what)                                                                       \
   do {                                                                                            \
     if ((expr) != PROVER_OK) throw std::runtime_error(std::string(what) + ": " + zkpoa_last_error(ctx)); \
   } while (0)
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char** argv) {
+  const bool verbose = getenv("ZKPOA_VERBOSE") && *getenv("ZKPOA_VERBOSE") && strcmp(getenv("ZKPOA_VERBOSE"), "0") != 0;
   std::string anon, poa, outdir;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -131,31 +270,35 @@ int main(int argc, char** argv) {
     printf("Initiating Merkle Tree build..\n");
     printf("Trying to read given file '\"%s\"'\n", anon.c_str());
     // csv: heading line "address,eth_balance", then 0x-prefixed hex address, decimal balance (merkle_tree.rs:212-246)
-    std::vector<uint64_t> addr, bal;
-    {
-      std::istringstream in(read_file(anon));
-      std::string line;
-      bool first = true;
-      while (std::getline(in, line)) {
-        if (trim(line).empty()) continue;
-        if (first) { first = false; continue; }
-        size_t comma = line.find(',');
-        if (comma == std::string::npos) throw std::runtime_error("Failed to find balance in line in csv file: " + line);
-        std::string a = trim(line.substr(0, comma)), b = trim(line.substr(comma + 1));
-        if (a.size() < 3 || a[0] != '0' || (a[1] != 'x' && a[1] != 'X')) throw std::runtime_error("address is not 0x-prefixed hex: " + a);
-        U256 av = parse_num(a.substr(2), 16, "address"), bv = parse_num(b, 10, "balance");
-        addr.insert(addr.end(), av.v, av.v + 4);
-        bal.insert(bal.end(), bv.v, bv.v + 4);
-      }
+    // the device context (HIP start-up, ~0.4 s) is created on a second thread while this one reads the set
+    char err[512] = {0};
+    long dev = 0;
+    if (const char* e = getenv("ZKPOA_DEVICE")) {
+      char* rest = nullptr;
+      dev = strtol(e, &rest, 10);
+      if (rest == e || *rest || dev < 0 || dev > 1023) throw std::runtime_error(std::string("ZKPOA_DEVICE: not a device index: ") + e);
     }
+    int ctx_rc = PROVER_OK;
+    std::thread ctx_thread([&] { ctx_rc = zkpoa_context_create((int)dev, &ctx, err, sizeof(err)); });
+    std::vector<uint64_t> addr, bal;
+    const double t0 = now_s();
+    try {
+      read_anonymity_set(anon, addr, bal);
+    } catch (...) {
+      ctx_thread.join();
+      throw;
+    }
+    const double t_read = now_s();
+    ctx_thread.join();
     const uint64_t n = addr.size() / 4;
     if (n == 0) throw std::runtime_error("the anonymity set is empty");
     printf("Converting lines in '\"%s\"' into leaf nodes.. (leaf node = hash(address, balance))\n", anon.c_str());
-    char err[512] = {0};
-    int dev = 0;
-    if (const char* e = getenv("ZKPOA_DEVICE")) dev = atoi(e);
-    if (zkpoa_context_create(dev, &ctx, err, sizeof(err)) != PROVER_OK) throw std::runtime_error(err);
+    if (ctx_rc != PROVER_OK) throw std::runtime_error(err);
+    const double t_ctx = now_s();
     ZK_CALL(zkpoa_merkle_build(ctx, addr.data(), bal.data(), n, &tree), "merkle tree build");
+    if (verbose)
+      fprintf(stderr, "merkle-tree: read %llu rows %.3f s, waited %.3f s more for the device, leaves + tree (with the upload) %.3f s\n",
+              (unsigned long long)n, t_read - t0, t_ctx - t_read, now_s() - t_ctx);
     uint64_t info[3];
     zkpoa_merkle_info(tree, info);
     printf("Done creating %llu leaves\n", (unsigned long long)n);
@@ -168,6 +311,7 @@ int main(int argc, char** argv) {
     write_file(root_path, "{\n  \"__bigint__\": \"" + root.dec() + "\"\n}");
     printf("Root hash %s written to file \"%s\"\n", root.dec().c_str(), root_path.c_str());
 
+    const double t_paths = now_s();
     // owned addresses: accountAttestations[].accountData.{address, balance}.__bigint__ (decimal), merkle_tree.rs:296-327
     JVal doc = zkpoa::json::parse_json(read_file(poa).c_str());
     const JVal& atts = doc.at("accountAttestations");
@@ -228,6 +372,7 @@ int main(int argc, char** argv) {
     }
     js += m ? "\n  ]\n}" : "]\n}";
     write_file(proofs_path, js);
+    if (verbose) fprintf(stderr, "merkle-tree: %llu paths and both files %.3f s\n", (unsigned long long)m, now_s() - t_paths);
   } catch (const std::exception& e) {
     fprintf(stderr, "Error: %s\n", e.what());
     rc = 1;
