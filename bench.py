@@ -123,6 +123,9 @@ PROVE_SHAPES = {
     25: (21356921, 2, "layer_two(2,12) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:33-39"),
     26: (61197000, 1, "synthetic layer_one(128 sigs) shape, tests/old/128_sigs/benchmarks.txt:4-10"),
     "26_l3": (52367163, 13, "layer_three(2) shape, tests/4_sigs_2_batches_12_height/benchmarks.txt:49-55"),
+    # beyond the reference's own runs: layer three grows by 24.2 M wires per batch (28.1 M at 1 batch, 52.4 M at 2:
+    # tests/{1_sigs_1_batches_5_height,4_sigs_2_batches_12_height}/benchmarks.txt), so 4 batches need a 2^27 domain
+    "27_l3": (100845225, 13, "layer_three(4 batches) shape, extrapolated from the reference's 1- and 2-batch runs"),
 }
 
 

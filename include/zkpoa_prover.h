@@ -383,9 +383,16 @@ int zkpoa_merkle_path(zkpoa_context* ctx, const zkpoa_merkle* tree, uint64_t lea
  *     6 = last prove: self-check (host pairing check; 0 when it did not run), 7 = last Merkle tree build.
  * Also: tuning knobs. key "msm_c" forces the Pippenger window (0 = auto); key "msm_max_points" sets the
  * number of points one bucket sort may take (0 = 2^27; larger MSMs run in chunks -- tests force small values);
- * key "prove_serial" = 1 runs the stages of a prove one after the other (solo device times for the roofline). */
+ * key "prove_serial" = 1 runs the stages of a prove one after the other (solo device times for the roofline);
+ * key "lane_workspace_max_mb" caps the workspace of every MSM lane (0 = none).
+ * Memory pressure: an MSM's workspace grows with the points it sorts at once (~0.4 GB per million at 2^26). When a
+ * lane's workspace does not fit -- HBM full (a 2^27 key, another process on the card) or over the cap above -- the MSM
+ * is not failed: it goes through its points in pieces of half the size (again halved if need be, down to 2^16), the
+ * context remembers the size that fitted, and the result is the same point. zkpoa_msm_points_limit() returns the
+ * number of points one MSM of this context sorts at once right now (2^27 until something did not fit). */
 float zkpoa_last_ms(const zkpoa_context* ctx, int id);
 int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value);
+uint64_t zkpoa_msm_points_limit(const zkpoa_context* ctx);
 
 /* ---- element-wise device hooks used by the parity tests ----------------------------------- */
 /* field: 0 = Fq, 1 = Fr. op: 0 = Montgomery mul, 1 = add, 2 = sub, 3 = inverse (b ignored),

@@ -71,6 +71,25 @@ def test_prove_layer_one_shape_all_points(ctx, zk):
     _prove_and_check_all(ctx, zk, 21, 2083343, 1, 0x5EED0010, oracle_h=True)
 
 
+def test_prove_layer_one_shape_under_memory_pressure(zk, capfd, monkeypatch):
+    """The same proof with every MSM lane's workspace capped at 500 MB (a whole 2 M-point sort needs ~1 GB): before the
+    proof starts the stages' workspaces are added up from their plans (csrc/prover.hip budget_lane_workspaces), the A, C
+    and H MSMs go through their points in pieces, the B query cannot be sorted once for B1 and B2 -- each sorts its own
+    pieces -- and all three proof points meet the known-dlog expectation. On a key of 2^27 constraints it is HBM itself
+    that runs out, and the same path runs (include/zkpoa_prover.h, "Memory pressure")."""
+    monkeypatch.setenv("ZKPOA_VERBOSE", "1")
+    c = zk.Context(0)
+    try:
+        c.set_option("lane_workspace_max_mb", 500)
+        _prove_and_check_all(c, zk, 21, 2083343, 1, 0x5EED0010, oracle_h=False)
+        assert c.msm_points_limit() <= 1 << 20
+    finally:
+        c.close()
+    err = capfd.readouterr().err
+    assert "HBM budget" in err, err     # decided before the proof from the stages' plans, not by failed reservations
+    assert "out of device memory" not in err and "over the lane limit" not in err, err
+
+
 @pytest.mark.parametrize("dist", ["uniform", "witness"])
 def test_msm_g2_full_size_known_dlog(ctx, dist):
     import torch
@@ -150,4 +169,16 @@ def test_layer_one_shape_through_the_file_boundary_on_several_ranks_vs_c_oracle(
         assert open(tmp_path / "public.json").read() == zk.public_to_json(want_pub, "rapidsnark")
         if "," in devices:
             assert "H-scalar chain split" in rc.stderr and "block-cyclic" in rc.stderr
+    # memory pressure on the one-shot path, whose stages learn their sizes as the file arrives: with every lane's workspace
+    # capped at 500 MB (ZKPOA_LANE_WORKSPACE_MAX_MB; a whole 2 M-point sort needs ~1 GB) each reservation that does not
+    # fit is answered by halving that MSM's piece, the B query falls back from its shared sort -- same proof
+    out = str(tmp_path / "proof_capped.json")
+    rc = subprocess.run([zk.PROVER_BIN, zp, wp, out, str(tmp_path / "public.json")],
+                        env=dict(base, ZKPOA_DEVICES="0", ZKPOA_LANE_WORKSPACE_MAX_MB="500"), capture_output=True, text=True, timeout=600)
+    assert rc.returncode == 0, rc.stderr
+    assert open(out).read() == want, "capped workspaces: proof differs from the C oracle's"
+    assert "B1 and B2 sort their own pieces" in rc.stderr and "continuing with at most" in rc.stderr, rc.stderr
+    rc = subprocess.run([zk.PROVER_BIN, zp, wp, out, str(tmp_path / "public.json")],
+                        env=dict(base, ZKPOA_DEVICES="0", ZKPOA_LANE_WORKSPACE_MAX_MB="lots"), capture_output=True, text=True, timeout=600)
+    assert rc.returncode != 0 and "ZKPOA_LANE_WORKSPACE_MAX_MB" in rc.stderr
     print("L1 shape through the file boundary on 1 / 2 / 4 ranks == C oracle (orc_prove %.1f s on %d threads)" % (t_cpu, THREADS))

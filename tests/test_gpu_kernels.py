@@ -167,6 +167,40 @@ def test_msm_chunked(ctx):
     assert got2 == co.msm_g2(b2, sc[:700 * 32], 700, 8)
 
 
+def test_msm_under_memory_pressure_goes_in_pieces(zk):
+    """A lane's workspace grows with the points sorted at once (~0.6-0.9 KB per point). When it does not fit -- here:
+    over a cap set with lane_workspace_max_mb, on a 2^27 key: HBM itself -- the MSM is not failed: it halves the piece
+    it sorts until the workspace fits, the context remembers that size, and the sum is the same point (known discrete
+    log, 3 x 2^20 + 5 points so that the last piece is ragged)."""
+    import torch
+    c = zk.Context(0)
+    try:
+        n = 3 * (1 << 20) + 5
+        a, b, d_bases = _dlog_setup(c, n, 41)
+        limbs = _np_scalars(n, 9, "witness")
+        d_sc = torch.from_numpy(limbs.view(np.uint8).reshape(-1).copy()).cuda()
+        want = bn.g1_mul(bn.G1_GEN, _dlog_expected(limbs, a, b))
+        assert c.msm_points_limit() == 1 << 27
+        c.set_option("lane_workspace_max_mb", 300)
+        assert g16.g1_from_bytes(c.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)) == want
+        lim = c.msm_points_limit()
+        assert (1 << 16) <= lim <= (1 << 19) and lim & (lim - 1) == 0      # 2^20 points need ~0.6 GB: at least 2 halvings
+        assert g16.g1_from_bytes(c.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)) == want   # remembered: no retry
+        assert c.msm_points_limit() == lim
+        c2 = zk.Context(0)                                                     # not even 2^16 points fit: an error, not a loop
+        try:
+            c2.set_option("lane_workspace_max_mb", 8)
+            with pytest.raises(zk.ZkpoaError, match="over the lane limit"):
+                c2.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)
+        finally:
+            c2.close()
+        c.set_option("lane_workspace_max_mb", 0)                               # cap lifted: whole MSMs again
+        assert c.msm_points_limit() == 1 << 27
+        assert g16.g1_from_bytes(c.msm_g1_device(d_bases.data_ptr(), d_sc.data_ptr(), n)) == want
+    finally:
+        c.close()
+
+
 def _dlog_setup(ctx, n, seed, group=1):
     import torch
     rng = random.Random(seed)

@@ -41,7 +41,7 @@ EXPORTS = [
     "zkpoa_msm_g1_device_lane", "zkpoa_last_ms_lane",
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
-    "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_field_op", "zkpoa_group_add",
+    "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_msm_points_limit", "zkpoa_field_op", "zkpoa_group_add",
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey", "zkpoa_zkey_export_vkey",
     "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
     "zkpoa_context_stream", "zkpoa_context_synchronize",
@@ -101,6 +101,8 @@ def lib():
         L.zkpoa_last_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.zkpoa_last_ms.restype = ctypes.c_float
         L.zkpoa_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]
+        L.zkpoa_msm_points_limit.argtypes = [ctypes.c_void_p]
+        L.zkpoa_msm_points_limit.restype = ctypes.c_uint64
         for name in ("zkpoa_msm_g1", "zkpoa_msm_g2", "zkpoa_msm_g1_device", "zkpoa_msm_g2_device"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                          ctypes.c_void_p]
@@ -245,6 +247,11 @@ class Context:
 
     def set_option(self, key, value):
         self._check(lib().zkpoa_set_option(self._h, key.encode(), int(value)), "zkpoa_set_option")
+
+    def msm_points_limit(self):
+        """Points one MSM of this context sorts at once right now: 2^27 until a lane's workspace did not fit in HBM (or
+        under option lane_workspace_max_mb), then the size that did (include/zkpoa_prover.h, "Memory pressure")."""
+        return int(lib().zkpoa_msm_points_limit(self._h))
 
     def last_ms(self, ident):
         return float(lib().zkpoa_last_ms(self._h, ident))

@@ -23,6 +23,11 @@ struct HipError : std::runtime_error {
   explicit HipError(const std::string& s) : std::runtime_error(s) {}
 };
 
+// a lane's workspace did not fit: the MSM drivers answer by working through the points in smaller pieces (msm_run)
+struct OomError : HipError {
+  explicit OomError(const std::string& s) : HipError(s) {}
+};
+
 #define ZK_HIP(expr)                                                                              \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
@@ -37,11 +42,22 @@ struct Arena {
   char* base = nullptr;
   size_t cap = 0;
   size_t off = 0;
+  size_t limit = 0;   // 0 = whatever HBM holds; else reserve() refuses more than this (option lane_workspace_max_mb)
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
+    if (limit && bytes > limit)
+      throw OomError("workspace of " + std::to_string(bytes >> 20) + " MiB is over the lane limit of " +
+                     std::to_string(limit >> 20) + " MiB");
     if (base) ZK_HIP(hipFree(base));
     base = nullptr;
-    ZK_HIP(hipMalloc(&base, bytes));
+    cap = off = 0;   // (a failed allocation below must not leave a capacity without memory behind it)
+    const hipError_t e = hipMalloc(&base, bytes);
+    if (e == hipErrorOutOfMemory) {
+      base = nullptr;
+      (void)hipGetLastError();   // the error is reported by the exception, not left behind for the next launch check
+      throw OomError("workspace of " + std::to_string(bytes >> 20) + " MiB: out of device memory");
+    }
+    ZK_HIP(e);
     cap = bytes;
   }
   void reset() { off = 0; }

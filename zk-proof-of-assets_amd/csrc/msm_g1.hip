@@ -37,6 +37,11 @@ void msm_density(hipStream_t st, const void* d_scalars, uint64_t n, double out[3
   ZK_HIP(hipStreamSynchronize(st));
   for (int c = kDensityLo; c <= kDensityHi; c++) out[c] = (double)h[c - kDensityLo] / (double)n;
 }
+size_t msm_workspace_g1(uint64_t n, int force_c, bool for_g2, int table_c, bool accum) {
+  if (n == 0) return 0;
+  const MsmPlan p = msm_make_plan((size_t)n, table_c > 0 ? table_c : force_c, for_g2, table_c > 0);
+  return msm_sort_workspace_bytes(p) + (accum ? msm_accum_workspace_bytes<Fq>(p) : 0);
+}
 void msm_table_info(const MsmTable* t, uint64_t out[4]) {
   out[0] = t->n;
   out[1] = t->c;

@@ -16,6 +16,11 @@ MsmTable* msm_table_build_g2(zkpoa_context* ctx, const void* d_bases, uint64_t n
   }
   return t;
 }
+size_t msm_workspace_g2(uint64_t n, int force_c, int table_c, bool sort) {
+  if (n == 0) return 0;
+  const MsmPlan p = msm_make_plan((size_t)n, table_c > 0 ? table_c : force_c, true, table_c > 0);
+  return (sort ? msm_sort_workspace_bytes(p) : 0) + msm_accum_workspace_bytes<Fq2>(p);
+}
 size_t msm_table_bytes_g2(uint64_t n, int c) { return msm_table_bytes<Fq2>(n, msm_table_c(n, c, true)); }
 void msm_accum_g2(zkpoa_context* ctx, int lane_id, const MsmSorted* sr, bool own_arena, const void* d_bases,
                   uint8_t* out, float* ms2) {

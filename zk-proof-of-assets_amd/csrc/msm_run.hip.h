@@ -15,19 +15,31 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   ctx->dev.ensure_lane(lane_id);
   Lane& lane = ctx->dev.lanes[lane_id];
   std::vector<char>& wsums = lane.host_sums;   // room for the largest read-back (msm_accum_phase checks it)
-  const uint64_t max_pts = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
-  if (table && (n > max_pts || table->n != n)) table = nullptr;   // a chunked MSM cannot index a whole-array table
   XYZZ<HF> total = XYZZ<HF>::inf();
   float tot_ms = 0, acc_sum = 0;
   uint64_t done = 0, adds = 0;
   do {
+    // (read every time round: a failed reservation below lowers it)
+    const uint64_t max_pts = ctx->msm_points_limit(lane_id);
+    if (table && (n > max_pts || table->n != n)) table = nullptr;   // a chunked MSM cannot index a whole-array table
     const uint64_t cnt = n - done < max_pts ? n - done : max_pts;
     float acc_ms = 0;
     uint32_t entries = 0;
     ZK_HIP(hipEventRecord(ctx->ev_a[lane_id], lane.stream));
-    MsmPlan p = msm_device<F>(lane, reinterpret_cast<const char*>(d_bases) + done * MsmSizes<F>::kAffine,
-                              reinterpret_cast<const char*>(d_scalars) + done * 32, (size_t)cnt, wsums.data(),
-                              ctx->opt_msm_c, &acc_ms, table, &entries);
+    MsmPlan p;
+    try {
+      p = msm_device<F>(lane, reinterpret_cast<const char*>(d_bases) + done * MsmSizes<F>::kAffine,
+                        reinterpret_cast<const char*>(d_scalars) + done * 32, (size_t)cnt, wsums.data(),
+                        ctx->opt_msm_c, &acc_ms, table, &entries);
+    } catch (const OomError& e) {
+      // HBM is full (a 2^27 key beside five whole-MSM workspaces; another process on the card): the workspace is
+      // proportional to the points sorted at once, so go through them in halves -- the sum is the same
+      if (!ctx->shrink_after_oom(lane_id, cnt)) throw;
+      if (getenv("ZKPOA_VERBOSE"))
+        fprintf(stderr, "zkpoa:   lane %d: %s for %llu points at once; continuing with at most %llu\n", lane_id, e.what(),
+                (unsigned long long)cnt, (unsigned long long)ctx->msm_points_limit(lane_id));
+      continue;
+    }
     adds += entries;
     ZK_HIP(hipEventRecord(ctx->ev_b[lane_id], lane.stream));
     ZK_HIP(hipEventSynchronize(ctx->ev_b[lane_id]));

@@ -844,6 +844,7 @@ bool split_h_partial(const zkpoa_zkey* zk) {
 // what exists and build at most that many more -- the resident prover builds a key's tables one per idle moment, so that
 // a request never waits for more than one of them (a whole set is 0.25 s at the layer-one shape, 3-7 s at layers two and
 // three: more than twenty proofs' worth, which a workflow of two batches never earns back on the request path).
+static size_t lane_workspace_total(const zkpoa_context* ctx, const zkpoa_zkey* zk, const uint64_t lim[5]);   // below
 uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, int max_new = -1) {
   const bool split = zk->split_world > 1;   // H table over the cyclic shard; A / B / C as for any shard
   ctx->dev.wait_lanes();
@@ -858,7 +859,13 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, in
     for (auto& l : ctx->dev.lanes) l.ws.release();
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
-    budget = (uint64_t)(0.5 * (double)free_b) + zk->table_bytes;
+    // ... but never the room the five lanes need for whole MSMs over this key (a chunked MSM cannot use its table, so
+    // a table that pushes its own MSM into pieces is HBM spent to be slower): at the reference's shapes the half is the
+    // smaller figure (2^26: ~100 GB of workspaces against 230 GB free); on a 2^27 key the workspaces come first
+    uint64_t lim[5];
+    for (int l = 0; l < 5; l++) lim[l] = ctx->msm_points_limit(l);
+    const double room = (double)free_b - 1.1 * (double)lane_workspace_total(ctx, zk, lim);
+    budget = (uint64_t)std::max(0.0, std::min(0.5 * (double)free_b, room)) + zk->table_bytes;
   }
   if (step) zk->table_budget = budget;
   const int force_c = ctx->opt_msm_c;
@@ -923,6 +930,111 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, in
   return zk->table_bytes;
 }
 
+// ---- HBM budget of the five MSM lanes ---------------------------------------------------------------------------
+// A lane's workspace is proportional to the points its MSM sorts at once (0.6-0.9 KB per point: 28 GB for the H MSM of a
+// 2^26 domain). At the reference's shapes (<= 2^26, 52 M wires) five whole-MSM workspaces, the key and its tables fit in
+// 288 GB with room to spare; a key of 2^27 constraints (layer three over four batches) or a card shared with another
+// process does not leave that room. The workspaces the stages of the coming proof would reserve (from their plans) are
+// therefore added up BEFORE a lane has to grow: if they do not fit in what is free (+ what the lanes hold now), the
+// stage with the largest workspace takes its points in halves -- again and again until the sum fits -- and the lanes
+// start from empty workspaces. A chunked MSM gives up its fixed-base table and the shared sort of the B query (each is
+// indexed by the whole array), so only the stages that must are chunked. What this cannot foresee (a staged one-shot
+// prove whose sizes arrive with the file, another process allocating meanwhile) is caught by the failed reservation
+// itself: msm_run.
+struct LaneNeeds {
+  size_t bytes[5] = {0, 0, 0, 0, 0};
+  size_t total() const { return bytes[0] + bytes[1] + bytes[2] + bytes[3] + bytes[4]; }
+};
+static LaneNeeds lane_needs(const zkpoa_context* ctx, const zkpoa_zkey* zk, const uint64_t lim[5], bool with_tables) {
+  LaneNeeds w;
+  const int fc = ctx->opt_msm_c;
+  const bool split = zk->split_world > 1;
+  auto table_c = [&](const MsmTable* t, uint64_t n, uint64_t limit) -> int {
+    if (!with_tables || !t || n > limit) return 0;
+    uint64_t info[4];
+    msm_table_info(t, info);
+    return info[0] == n ? (int)info[1] : 0;
+  };
+  const double* dens = zk->have_density ? zk->witness_density : nullptr;
+  // H (lane 0): uniform scalars
+  msm_set_density_hint(nullptr);
+  const uint64_t nH = split ? (uint64_t)(zk->domain >> zk->split_log) : zk->hcnt;
+  w.bytes[0] = msm_workspace_g1(std::min(nH, lim[0]), fc, false, table_c(zk->tH, nH, lim[0]), true);
+  // A (lane 1), C (lane 4): witness scalars
+  msm_set_density_hint(dens);
+  w.bytes[1] = msm_workspace_g1(std::min(zk->qA.cnt, lim[1]), fc, false, table_c(zk->tA, zk->qA.cnt, lim[1]), true);
+  w.bytes[4] = msm_workspace_g1(std::min(zk->ccnt, lim[4]), fc, false, table_c(zk->tC, zk->ccnt, lim[4]), true);
+  // B (lanes 2 and 3): one sort for both when the whole query fits one
+  const uint64_t nB = zk->qB.cnt, limB = std::min(lim[2], lim[3]);
+  if (nB <= limB) {
+    const int tc = (zk->tB1 && zk->tB2) ? table_c(zk->tB1, nB, limB) : 0;
+    w.bytes[2] = msm_workspace_g1(nB, fc, true, tc, true);
+    w.bytes[3] = msm_workspace_g2(nB, fc, tc, false);
+  } else {
+    w.bytes[2] = msm_workspace_g1(std::min(nB, lim[2]), fc, false, 0, true);
+    w.bytes[3] = msm_workspace_g2(std::min(nB, lim[3]), fc, 0, true);
+  }
+  msm_set_density_hint(nullptr);
+  return w;
+}
+
+static size_t lane_workspace_total(const zkpoa_context* ctx, const zkpoa_zkey* zk, const uint64_t lim[5]) {
+  return lane_needs(ctx, zk, lim, false).total();   // classic form: what the lanes need if no table is built
+}
+
+static void budget_lane_workspaces(zkpoa_context* ctx, const zkpoa_zkey* zk) {
+  uint64_t lim[5];
+  for (int l = 0; l < 5; l++) lim[l] = ctx->msm_points_limit(l);
+  LaneNeeds w = lane_needs(ctx, zk, lim, true);
+  size_t held = 0, after = 0;
+  bool grow = false, over_cap = false;
+  for (int l = 0; l < 5; l++) {
+    const Arena& a = ctx->dev.lanes[l].ws;
+    held += a.cap;
+    after += std::max(a.cap, w.bytes[l]);
+    grow = grow || w.bytes[l] > a.cap;
+    over_cap = over_cap || (a.limit && w.bytes[l] > a.cap && w.bytes[l] > a.limit);
+  }
+  if (!grow) return;   // (the steady state: nothing below runs, no driver call)
+  size_t free_b = 0, total_b = 0;
+  ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+  const double keep = 0.95;   // of what is free: the proof's own temporaries are small beside the workspaces
+  if (!over_cap && (double)(after - held) <= keep * (double)free_b) return;
+  const double avail = keep * ((double)free_b + (double)held);
+  auto fits = [&](const LaneNeeds& x) {
+    for (int l = 0; l < 5; l++)
+      if (ctx->dev.lanes[l].ws.limit && x.bytes[l] > ctx->dev.lanes[l].ws.limit) return false;
+    return (double)x.total() <= avail;
+  };
+  const uint64_t n_of[5] = {zk->split_world > 1 ? (uint64_t)(zk->domain >> zk->split_log) : zk->hcnt, zk->qA.cnt,
+                            zk->qB.cnt, zk->qB.cnt, zk->ccnt};
+  while (!fits(w)) {
+    // the lane that is over its cap first, else the one with the largest workspace; its MSM takes half as many points
+    int pick = -1;
+    for (int l = 0; l < 5; l++)
+      if (ctx->dev.lanes[l].ws.limit && w.bytes[l] > ctx->dev.lanes[l].ws.limit && (pick < 0 || w.bytes[l] > w.bytes[pick]))
+        pick = l;
+    if (pick < 0)
+      for (int l = 0; l < 5; l++)
+        if (std::min(n_of[l], lim[l]) > (1ull << 16) && (pick < 0 || w.bytes[l] > w.bytes[pick])) pick = l;
+    if (pick < 0 || std::min(n_of[pick], lim[pick]) <= (1ull << 16)) break;   // nothing left to halve: the reservation will say so
+    lim[pick] = zkpoa_context::below(std::min(n_of[pick], lim[pick]));
+    w = lane_needs(ctx, zk, lim, true);
+  }
+  for (int l = 0; l < 5; l++)
+    if (lim[l] < ctx->msm_points_limit(l)) ctx->oom_max_points[l] = lim[l];
+  for (int l = 0; l < 5; l++) {   // every lane starts again from what it needs now (nothing is in flight: prove start)
+    ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[l].stream));
+    ctx->dev.lanes[l].ws.release();
+  }
+  if (getenv("ZKPOA_VERBOSE"))
+    fprintf(stderr,
+            "zkpoa:   HBM budget: %.1f GB free + %.1f GB held by the lanes; MSMs take at most H %llu, A %llu, B1 %llu, B2 %llu, "
+            "C %llu points at once (workspaces %.1f GB)\n",
+            free_b / 1e9, held / 1e9, (unsigned long long)lim[0], (unsigned long long)lim[1], (unsigned long long)lim[2],
+            (unsigned long long)lim[3], (unsigned long long)lim[4], w.total() / 1e9);
+}
+
 // Partial MSM results of this handle's shard: A(64) B1(64) B2(128) C(64) H(64). The witness is already
 // in zk->d_witness (device). The H-scalar chain runs in full on every rank (replicated).
 // Hooks of a one-shot prove that overlaps the key upload with the compute (load_prove_staged): each stage of
@@ -983,6 +1095,12 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
     });
     return zk->have_density ? zk->witness_density : nullptr;
   };
+  // HBM budget of the lanes (a staged prove learns its sizes as the file arrives: msm_run's retry instead). A key's
+  // first proof measures the witness's digit density first -- the witness MSMs are planned, and sized, with it
+  if (!stg) {
+    if (!zk->have_density) (void)with_density(1);
+    budget_lane_workspaces(ctx, zk);
+  }
   auto gather = [&](int lane_id, const zkpoa_zkey::CompactQuery& q) {
     if (q.cnt)
       hipLaunchKernelGGL(gather32_kernel, dim3((uint32_t)((q.cnt * 2 + 255) / 256)), dim3(256), 0,
@@ -1004,7 +1122,8 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   });
   if (serial) tA.join();
   // (a B query beyond the 32-bit entry index of one sort cannot share it: two chunked MSMs instead)
-  const uint64_t sort_limit = ctx->opt_msm_max_points ? (uint64_t)ctx->opt_msm_max_points : (1ull << 27);
+  // (nor can one whose whole-query workspace did not fit in HBM on an earlier MSM of this context: msm_points_limit)
+  const uint64_t sort_limit = std::min(ctx->msm_points_limit(2), ctx->msm_points_limit(3));
   bool share_b = false;      // set by the B1 stage, read by the B2 stage after the sort has been published
   int table_c_b = 0;
   float sort_b_ms = 0;   // the shared sort of the B query (host clock: the call returns with its stream synchronised)
@@ -1024,8 +1143,17 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
       msm_set_density_hint(with_density(2));
       gather(2, zk->qB);
       auto ts0 = std::chrono::steady_clock::now();
-      if (share_b) sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
-      else ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[2].stream));   // the gathered scalars are read on lane 3 too
+      if (share_b) {
+        try {
+          sr = msm_sort_run(ctx, 2, zk->qB.scalars, zk->qB.cnt, true, table_c_b);
+        } catch (const OomError& e) {   // no room for the whole query's sort: B1 and B2 each go through it in pieces
+          if (!ctx->shrink_after_oom(2, zk->qB.cnt)) throw;
+          if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa:   B query: %s; B1 and B2 sort their own pieces\n", e.what());
+          share_b = false;
+          table_c_b = 0;
+        }
+      }
+      if (!share_b) ZK_HIP(hipStreamSynchronize(ctx->dev.lanes[2].stream));   // the gathered scalars are read on lane 3 too
       sort_b_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - ts0).count();
       sorted_promise.set_value(sr);
     } catch (...) {
@@ -1040,8 +1168,17 @@ void prove_partials(zkpoa_context* ctx, const zkpoa_zkey* zk, uint8_t out[384], 
   std::thread tB2 = guarded(2, [&] {
     const MsmSorted* sr = sorted_ready.get();
     const char* pB2 = reinterpret_cast<const char*>(zk->qB.g2) + zk->qB.lo * 128;
-    if (share_b) msm_accum_g2(ctx, 3, sr, false, table_c_b ? msm_table_data(zk->tB2) : pB2, outB2, msm_ms[3]);
-    else msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
+    bool shared = share_b;
+    if (shared) {
+      try {
+        msm_accum_g2(ctx, 3, sr, false, table_c_b ? msm_table_data(zk->tB2) : pB2, outB2, msm_ms[3]);
+      } catch (const OomError& e) {   // the G2 buckets of the whole query did not fit beside the rest: own sort, in pieces
+        if (!ctx->shrink_after_oom(3, zk->qB.cnt)) throw;
+        if (getenv("ZKPOA_VERBOSE")) fprintf(stderr, "zkpoa:   B2: %s; sorting its own pieces\n", e.what());
+        shared = false;
+      }
+    }
+    if (!shared) msm_run_g2(ctx, 3, pB2, zk->qB.scalars, zk->qB.cnt, outB2, msm_ms[3]);
   });
   if (serial) tB2.join();
   std::thread tC = guarded(3, [&] {

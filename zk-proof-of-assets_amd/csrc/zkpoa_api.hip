@@ -30,6 +30,16 @@ extern "C" int zkpoa_context_create(int device, zkpoa_context** out, char* error
     c->dev.after_copy_stream = [c, device](hipStream_t st) { c->uploader.prepare(device, st); };
     c->dev.after_lanes = [c, device] { c->uploader.add_streams(device); };
     c->dev.init(device);
+    // cap of every MSM lane's workspace (as option lane_workspace_max_mb): a card shared with other work
+    if (const char* e = getenv("ZKPOA_LANE_WORKSPACE_MAX_MB")) {
+      if (*e) {
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end == e || *end || v < 0 || v > (1l << 20))
+          throw std::runtime_error(std::string("ZKPOA_LANE_WORKSPACE_MAX_MB='") + e + "' is not a number of MiB");
+        for (auto& l : c->dev.lanes) l.ws.limit = (size_t)v << 20;
+      }
+    }
     for (int i = 0; i < DeviceCtx::kLanes; i++) {
       ZK_HIP(hipEventCreate(&c->ev_a[i]));
       ZK_HIP(hipEventCreate(&c->ev_b[i]));
@@ -69,6 +79,8 @@ extern "C" float zkpoa_last_ms(const zkpoa_context* ctx, int id) {
   return ctx->ms[id];
 }
 
+extern "C" uint64_t zkpoa_msm_points_limit(const zkpoa_context* ctx) { return ctx ? ctx->msm_points_limit_min() : 0; }
+
 extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value) {
   if (!ctx || !key) return PROVER_ERROR;
   if (!strcmp(key, "msm_c")) {
@@ -91,6 +103,12 @@ extern "C" int zkpoa_set_option(zkpoa_context* ctx, const char* key, long value)
   if (!strcmp(key, "scan_poll_limit_log2")) {   // polls of one status word before a scan look-back gives up (default 24)
     if (value < 4 || value > 30) return PROVER_ERROR;
     for (auto& l : ctx->dev.lanes) l.scan_poll_limit = 1u << value;
+    return PROVER_OK;
+  }
+  if (!strcmp(key, "lane_workspace_max_mb")) {  // cap of every MSM lane's workspace (0 = none): an MSM whose sort does
+    if (value < 0) return PROVER_ERROR;         // not fit under it goes through its points in pieces (msm_run)
+    for (auto& l : ctx->dev.lanes) l.ws.limit = (size_t)value << 20;
+    for (auto& o : ctx->oom_max_points) o = 0;
     return PROVER_OK;
   }
   if (!strcmp(key, "scan_test_withhold")) {     // tests only: tile 0 of every scan withholds its prefix

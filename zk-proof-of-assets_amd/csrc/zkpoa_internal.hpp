@@ -5,6 +5,8 @@
 #include "fast_upload.hpp"
 #include "host_curve.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,34 @@ struct zkpoa_context {
   double lane_adds[zkpoa::DeviceCtx::kLanes] = {};   // per-lane mixed additions of that kernel (non-zero digits)
   int opt_msm_c = 0;
   long opt_msm_max_points = 0;   // 0 = default (2^27): larger MSMs run in chunks
+  // Set when a lane's workspace for a whole MSM did not fit in HBM (found out by a failed reservation: msm_run, or
+  // ahead of a proof: prover.hip budget_lane_workspaces): from then on the MSMs of that lane take at most this many
+  // points at a time (never below 2^16); 0 = no limit of this kind.
+  std::atomic<uint64_t> oom_max_points[zkpoa::DeviceCtx::kLanes] = {};
+  uint64_t msm_points_limit(int lane) const {
+    uint64_t lim = opt_msm_max_points ? (uint64_t)opt_msm_max_points : (1ull << 27);
+    const uint64_t o = oom_max_points[lane].load();
+    return o && o < lim ? o : lim;
+  }
+  uint64_t msm_points_limit_min() const {
+    uint64_t lim = msm_points_limit(0);
+    for (int l = 1; l < zkpoa::DeviceCtx::kLanes; l++) lim = std::min(lim, msm_points_limit(l));
+    return lim;
+  }
+  static uint64_t below(uint64_t points) {   // the largest power of two below `points`, at least 2^16
+    uint64_t want = 1ull << 16;
+    while (want * 2 < points) want *= 2;
+    return want;
+  }
+  // called with the size that failed; false when there is nothing smaller to try
+  bool shrink_after_oom(int lane, uint64_t failed_points) {
+    if (failed_points <= (1ull << 16)) return false;
+    const uint64_t want = below(failed_points);
+    uint64_t cur = oom_max_points[lane].load();
+    while ((cur == 0 || cur > want) && !oom_max_points[lane].compare_exchange_weak(cur, want)) {
+    }
+    return true;
+  }
   int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
   // split chain: the witness copy of zkpoa_split_stage1 is enqueued on lane 0; the other lanes' MSMs wait for it
   hipEvent_t ev_witness = nullptr;
@@ -78,6 +108,12 @@ uint32_t msm_table_width(uint64_t n, int c, bool g2);
 void msm_table_release(MsmTable* t);
 const void* msm_table_data(const MsmTable* t);
 void msm_table_info(const MsmTable* t, uint64_t out[4]);   // n, c, W, bytes
+// bytes of lane workspace an MSM over n points reserves (msm.hip.h msm_sort/accum_workspace_bytes of its plan, which
+// follows the calling thread's density hint). g1: bucket sort (for_g2: one that also feeds a G2 accumulation) and, with
+// `accum`, the G1 accumulation in the same arena; g2: the G2 accumulation and, with `sort`, its own sort.
+// table_c > 0: the fixed-base form with that window width.
+size_t msm_workspace_g1(uint64_t n, int force_c, bool for_g2, int table_c, bool accum);
+size_t msm_workspace_g2(uint64_t n, int force_c, int table_c, bool sort);
 void msm_set_forced_k0(int k0);
 // non-zero digits per scalar for every window width (index c, 4..25) of n scalars on the device; synchronises st
 // (d_scratch: 256 B of device memory of the caller's -- no allocation here: a hipFree would wait for every lane)
