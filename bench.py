@@ -126,6 +126,8 @@ PROVE_SHAPES = {
     # beyond the reference's own runs: layer three grows by 24.2 M wires per batch (28.1 M at 1 batch, 52.4 M at 2:
     # tests/{1_sigs_1_batches_5_height,4_sigs_2_batches_12_height}/benchmarks.txt), so 4 batches need a 2^27 domain
     "27_l3": (100845225, 13, "layer_three(4 batches) shape, extrapolated from the reference's 1- and 2-batch runs"),
+    # the largest domain the proving system has (Fr has 2^28-th roots of unity only): layer three over 8 batches
+    "28_l3": (197801349, 13, "layer_three(8 batches) shape, extrapolated likewise; 2^28 = the largest Groth16 domain over BN254"),
 }
 
 

@@ -136,6 +136,19 @@ def test_prove_2p26_all_points(ctx, zk):
     _prove_and_check_all(ctx, zk, 26, 61197000, 1, 0x5EED0010, oracle_h=False)
 
 
+@pytest.mark.skipif(os.environ.get("ZKPOA_TEST_2P27") != "1", reason="opt-in (ZKPOA_TEST_2P27=1): ~2 minutes, ~60 GB of host memory")
+def test_prove_2p27_layer_three_of_four_batches_shape(zk):
+    """Beyond the reference's own runs: layer three grows by 24.2 M wires per batch, so four batches need a 2^27 domain
+    (100.8 M wires). Key, chain buffers and five whole-MSM workspaces are then ~250 GB: the lanes' HBM budget
+    (csrc/prover.hip budget_lane_workspaces) decides which MSMs go in pieces. Same checks as every other shape.
+    (bench.py --workload prove_2p27_l3 / prove_2p28_l3 run the same checks: profiles/r04_bench_prove_2p2{7,8}_l3.json.log.)"""
+    c = zk.Context(0)
+    try:
+        _prove_and_check_all(c, zk, 27, 100845225, 13, 0x5EED0027, oracle_h=False)
+    finally:
+        c.close()
+
+
 def test_layer_one_shape_through_the_file_boundary_on_several_ranks_vs_c_oracle(ctx, zk, tmp_path):
     """BASELINE.json configs[3], layer-one leg, through the boundary the reference really has
     (scripts/g16_prove.sh:248-252 execs `prover <zkey> <wtns> <proof.json> <public.json>`; one such process per batch,
