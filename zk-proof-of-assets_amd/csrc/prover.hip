@@ -854,11 +854,16 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, in
   bool deferred = false;
   if (!step) zk->release_tables();
   if (step && zk->table_budget) budget = zk->table_budget;
+  bool release_lanes = false;
+  size_t held = 0;
   if (budget == 0) {
-    // the lanes' grow-only workspaces are given back first (they regrow to what the fixed-base plans need)
-    for (auto& l : ctx->dev.lanes) l.ws.release();
+    // the lanes' grow-only workspaces are given back first (they regrow to what the fixed-base plans need) -- counted
+    // as free here, released below once it is known that a table will be built at all
+    for (auto& l : ctx->dev.lanes) held += l.ws.cap;
+    release_lanes = true;
     size_t free_b = 0, total_b = 0;
     ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += held;
     // ... but never the room the five lanes need for whole MSMs over this key (a chunked MSM cannot use its table, so
     // a table that pushes its own MSM into pieces is HBM spent to be slower): at the reference's shapes the half is the
     // smaller figure (2^26: ~100 GB of workspaces against 230 GB free); on a 2^27 key the workspaces come first
@@ -900,18 +905,30 @@ uint64_t zkey_precompute(zkpoa_context* ctx, zkpoa_zkey* zk, uint64_t budget, in
     return c;
   };
   msm_set_density_hint(nullptr);
+  const int cC = nC ? witness_c(nC, false) : 0, cA = nA ? witness_c(nA, false) : 0, cB = nB ? witness_c(nB, true) : 0;
+  if (release_lanes) {
+    // Nothing to build (a 2^27 key: the lanes' workspaces come first): keep the workspaces. Giving back 150 GB and
+    // taking it again costs seconds -- the driver wipes released memory before it hands it out (measured: 5 s per lane).
+    const bool any = (!zk->tH && nH && (split || zk->hlo == zk->hbase) && fits(msm_table_bytes_g1(nH, force_c))) ||
+                     (!zk->tC && nC && zk->clo == zk->cbase && fits(msm_table_bytes_g1(nC, cC))) ||
+                     (!zk->tA && nA && fits(msm_table_bytes_g1(nA, cA))) ||
+                     (!(zk->tB1 && zk->tB2) && nB && fits(msm_table_bytes_g1(nB, cB) + msm_table_bytes_g2(nB, cB)));
+    if (!any) {
+      zk->tables_settled = true;
+      return zk->table_bytes;
+    }
+    for (auto& l : ctx->dev.lanes) l.ws.release();
+  }
   bool more = true;
   // (a table that exists already counts as fitting: its bytes are in table_bytes)
   if (more && nH && (split || zk->hlo == zk->hbase) && (zk->tH || fits(msm_table_bytes_g1(nH, force_c)))) {
     more = build(&zk->tH, false, split ? zk->dHs : zk->dH, nH, force_c);
     zk->tH_cyclic = split && zk->tH;
   }
-  const int cC = nC ? witness_c(nC, false) : 0, cA = nA ? witness_c(nA, false) : 0;
   if (more && nC && zk->clo == zk->cbase && (zk->tC || fits(msm_table_bytes_g1(nC, cC)))) more = build(&zk->tC, false, zk->dC, nC, cC);
   if (more && nA && (zk->tA || fits(msm_table_bytes_g1(nA, cA)))) more = build(&zk->tA, false, zk->qA.g1, nA, cA);
   if (more && nB && !(zk->tB1 && zk->tB2)) {
-    // one window width for both B tables: the G2 model's (shorter pieces), as the shared sort is planned for G2
-    const int cB = witness_c(nB, true);
+    // (one window width for both B tables: the G2 model's -- shorter pieces -- as the shared sort is planned for G2)
     if (step && built >= max_new) {   // the pair is one step's work
       more = false;
       deferred = true;
