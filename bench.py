@@ -27,12 +27,14 @@ sys.path.insert(0, ROOT)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
-VALU_PEAK_GADDS = 13.6      # XYZZ mixed additions/s the integer pipe allows on one MI355X, from the measured rates of its parts
-                            # (tools/microbench.hip, r03, 8 waves/SIMD): 8 products at 139.8 G/s + 2 squares at 170.2 G/s + 7
-                            # additions / subtractions of 24 instructions each (0.62 of a product's 272) = 73.4 ps per addition.
-                            # The register-only loop of the same addition reaches 12.6 G/s at 4 waves/SIMD (12.15 at 3) and was
-                            # r02's "peak" -- the kernel, whose base loads hide under the arithmetic, runs above it, so it was
-                            # not a ceiling
+VALU_PEAK_GADDS = 14.2      # XYZZ mixed additions/s the integer pipe allows on one MI355X, from the measured rates of its parts
+                            # (tools/microbench.hip, profiles/r03_microbench.txt, 8 waves/SIMD): 6 products at 139.8 G/s + one
+                            # sum of two products under a single reduction (y3: Fq::dot2, half an Fq2 product: 90.6 G/s) + 2
+                            # squares at 170.2 G/s + 7 additions / subtractions / negations of ~24 instructions each (0.09 of
+                            # a product's 272) = 70.3 ps per addition. Until r04's y3 change the addition had 8 products
+                            # (73.4 ps: 13.6 G/s, the peak of every earlier line). The register-only loop of the addition
+                            # was r02's "peak" -- the kernel, whose base loads hide under the arithmetic, runs above it, so it
+                            # was not a ceiling
 G2_VALU_PEAK_GADDS = 4.67   # the same bound for the G2 mixed addition: 8 Fq2 products at 45.3 G/s (176.6 ps) + 2 Fq2 squares =
                             # 4 Fq products at 139.8 G/s (28.6 ps) + 14 Fq additions / subtractions of 24 instructions, 0.088
                             # of a product each (8.9 ps) = 214 ps (profiles/r03_microbench.txt; VERDICT r03 quoted 3.74 from a
@@ -575,7 +577,7 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
                 "phase_ms_overlapped": {kk: v / steps for kk, v in acc.items()}}
         if solo is not None:
             # the accumulation kernels of the five MSMs against the integer pipe: G1 against the
-            # 13.6 G additions/s its parts allow, the G2 one (B2) against 4.67 G/s (8 Fq2 products at 45.3 G/s + 2 Fq2
+            # 14.2 G additions/s its parts allow, the G2 one (B2) against 4.67 G/s (8 Fq2 products at 45.3 G/s + 2 Fq2
             # squares + 14 Fq additions, tools/microbench.hip) -- it runs at 2 waves per SIMD, where one wave's issue
             # rate, not the pipe, sets the pace
             roof["valu_accum"] = {

@@ -98,9 +98,17 @@ ZK_HD void xyzz_add_affine(XYZZ<F>& acc, const Affine<F>& p_in, bool negate) {
     Fq::sqr_pair(pp_, r, pp, rr);
     Fq::mul_pair(pp_, pp, acc.x, pp, ppp, q);
     F x3 = rr - ppp - q.dbl();
+#if defined(ZKPOA_G1_Y3_TWO_PRODUCTS)
     Fq::mul_pair(r, q - x3, acc.y, ppp, t0, t1);
-    acc.x = x3;
     acc.y = t0 - t1;
+#else
+    // y3 = r (q - x3) - y1 ppp as ONE sum of two products with one Montgomery reduction (Fq::dot2, as the Fq2 product):
+    // 9 reductions per addition instead of 10, and no subtraction afterwards
+    (void)t0;
+    (void)t1;
+    acc.y = Fq::dot2(r, q - x3, acc.y.neg_2p(), ppp);
+#endif
+    acc.x = x3;
     Fq::mul_pair(acc.zz, pp, acc.zzz, ppp, acc.zz, acc.zzz);
     return;
   }
@@ -148,7 +156,12 @@ ZK_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
   F ppp = pp_ * pp;
   F q = u1 * pp;
   F x3 = r.sqr() - ppp - q.dbl();
-  F y3 = r * (q - x3) - s1 * ppp;
+  F y3;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKPOA_G1_Y3_TWO_PRODUCTS)
+  if constexpr (std::is_same<F, Fq>::value) y3 = Fq::dot2(r, q - x3, s1.neg_2p(), ppp);   // one reduction, as xyzz_add_affine
+  else
+#endif
+    y3 = r * (q - x3) - s1 * ppp;
   acc.x = x3;
   acc.y = y3;
   acc.zz = acc.zz * b.zz * pp;
