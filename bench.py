@@ -620,8 +620,13 @@ def prove_leg(env, k, steps, warmup, precompute=True, cpu_baseline=False, serial
 # ---------------------------------------------------------------------------------------------------------------
 MODMUL_PEAK_G = 140.0       # 254-bit Montgomery products/s, register-only loop on one MI355X (tools/microbench.hip, r03: a * a
                             # 139.8 G/s at 8 waves/SIMD, the dedicated square 170.2 G/s; r02 quoted 130 from 4 waves/SIMD)
-POSEIDON_MODMULS = 8 * 18 + 4 + 57 * 8 + 3   # per hash as the kernel computes it: full rounds 3 S-boxes + 9 MDS products,
-                                            # one 2 x 2 product, sparse partial rounds 3 + 5, form changes (poseidon.hip)
+# One hash as the kernel computes it (poseidon.hip), in multiply-accumulate pairs (v_mad_u64_u32 + v_addc): a product is
+# 64 + 72 (the Montgomery reduction), a square 36 + 72, a row of the 3 x 3 MDS product ONE sum of three products under a
+# single reduction (r04: Fr::dot3, 192 + 72 -- it was three products, 408), the 2 x 2 product of the form change two sums
+# of two (200 each). Full round: 3 S-boxes (2 squares + 1 product) + 3 rows; sparse partial round: 1 S-box + 1 row + 2
+# products; + 3 products of form changes. Expressed in products of 136 pairs: the VALU ceiling is MODMUL_PEAK_G / that.
+POSEIDON_MAC_PAIRS = 8 * (3 * (2 * 108 + 136) + 3 * 264) + 2 * 200 + 57 * ((2 * 108 + 136) + 264 + 2 * 136) + 3 * 136
+POSEIDON_MODMULS = POSEIDON_MAC_PAIRS / 136.0   # 486.8 (r03: 607 products, every one with its own reduction)
 
 
 def merkle_leg(env, n_leaves, steps, warmup, cpu_baseline=True):
@@ -691,8 +696,9 @@ def merkle_leg(env, n_leaves, steps, warmup, cpu_baseline=True):
                      "valu": {"unit": "G modmul/s", "achieved": POSEIDON_MODMULS * hashes / kernel_s / 1e9,
                               "peak": MODMUL_PEAK_G, "frac": POSEIDON_MODMULS * hashes / kernel_s / 1e9 / MODMUL_PEAK_G,
                               "hashes_per_s": hashes / kernel_s, "modmul_per_hash": POSEIDON_MODMULS},
-                     "note": "algorithmic bytes = 64 B in + 32 B out per hash; the hash is %d Montgomery products: "
-                             "integer-VALU-bound" % POSEIDON_MODMULS},
+                     "note": "algorithmic bytes = 64 B in + 32 B out per hash; the hash is %d multiply-accumulate pairs = %.1f "
+                             "Montgomery products' worth (sums of products share one reduction): integer-VALU-bound"
+                             % (POSEIDON_MAC_PAIRS, POSEIDON_MODMULS)},
     }
     if cpu_baseline:
         cores = host_cores()

@@ -246,9 +246,11 @@ ZK_DEV void full_round(const PoseidonTables* __restrict__ prm, int k, Fr& s0, Fr
   s0 = pow5(s0 + prm->Cf[k][0]);
   s1 = pow5(s1 + prm->Cf[k][1]);
   s2 = pow5(s2 + prm->Cf[k][2]);
-  Fr n0 = prm->M[0][0] * s0 + prm->M[0][1] * s1 + prm->M[0][2] * s2;
-  Fr n1 = prm->M[1][0] * s0 + prm->M[1][1] * s1 + prm->M[1][2] * s2;
-  Fr n2 = prm->M[2][0] * s0 + prm->M[2][1] * s1 + prm->M[2][2] * s2;
+  // every row of the MDS product is one sum of three products under a single Montgomery reduction (Fr::dot3: the
+  // matrix entries are canonical, the state lazily reduced) -- 3 reductions per round instead of 9
+  Fr n0 = Fr::dot3(s0, prm->M[0][0], s1, prm->M[0][1], s2, prm->M[0][2]);
+  Fr n1 = Fr::dot3(s0, prm->M[1][0], s1, prm->M[1][1], s2, prm->M[1][2]);
+  Fr n2 = Fr::dot3(s0, prm->M[2][0], s1, prm->M[2][1], s2, prm->M[2][2]);
   s0 = n0;
   s1 = n1;
   s2 = n2;
@@ -262,14 +264,14 @@ ZK_DEV Fr poseidon2(const PoseidonTables* __restrict__ prm, const Fr& left, cons
   s1 = s1 + prm->Cmid[1];
   s2 = s2 + prm->Cmid[2];
   {
-    Fr n1 = s1 * prm->Mhat[0][0] + s2 * prm->Mhat[1][0];
-    Fr n2 = s1 * prm->Mhat[0][1] + s2 * prm->Mhat[1][1];
+    Fr n1 = Fr::dot2(s1, prm->Mhat[0][0], s2, prm->Mhat[1][0]);
+    Fr n2 = Fr::dot2(s1, prm->Mhat[0][1], s2, prm->Mhat[1][1]);
     s1 = n1;
     s2 = n2;
   }
   for (int r = 0; r < kRP; r++) {
     s0 = pow5(s0) + prm->C0[r];
-    Fr n0 = s0 * prm->M[0][0] + s1 * prm->W[r][0] + s2 * prm->W[r][1];
+    Fr n0 = Fr::dot3(s0, prm->M[0][0], s1, prm->W[r][0], s2, prm->W[r][1]);
     s1 = s1 + s0 * prm->V[r][0];
     s2 = s2 + s0 * prm->V[r][1];
     s0 = n0;
