@@ -100,6 +100,17 @@ def test_cli_usage_error(zk):
     assert rc.returncode != 0 and "Usage" in rc.stderr
 
 
+def test_cli_worker_process_reports_a_failure(zk, tmp_path):
+    """`prover` with a worker process (ZKPOA_DETACH_EXIT=always; by default for keys of 2 GB or more): an input error in
+    the worker is this command's exit status and message, and nothing is left behind. No GPU needed to get that far."""
+    (tmp_path / "c.zkey").write_bytes(b"zkey" + bytes(40))
+    rc = subprocess.run([zk.PROVER_BIN, str(tmp_path / "c.zkey"), str(tmp_path / "missing.wtns"), str(tmp_path / "p.json"),
+                         str(tmp_path / "q.json")], env=dict(os.environ, ZKPOA_DETACH_EXIT="always"), capture_output=True,
+                        text=True, timeout=60)
+    assert rc.returncode == 1 and "cannot read witness file" in rc.stderr
+    assert not (tmp_path / "p.json").exists() and not (tmp_path / "q.json").exists()
+
+
 def test_product_does_not_reference_oracle():
     """The product tree must not import, link or execute anything under oracle/."""
     bad = []

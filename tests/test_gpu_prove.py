@@ -348,6 +348,32 @@ def test_prover_cli_drop_in(zk, tmp_path):
     assert (tmp_path / "public_s.json").read_text() == g["public_snarkjs.json"]
 
 
+def test_prover_cli_worker_process_for_large_keys(zk, tmp_path):
+    """A key of 2 GB or more is proved by a worker process and `prover` itself leaves as soon as both outputs are in place
+    (the kernel needs ~150 ms to dismantle a process holding a 13-30 GB key on the GPU; csrc/prover_main.hip). Forced here
+    for a small key with ZKPOA_DETACH_EXIT=always: same files, same exit status, the caller's pipes are released (this
+    call returns), a failure still arrives as a non-zero status with its message and no output file; =0 keeps one process."""
+    g = golden_case("n128")
+    rs = json.loads(g["rs.json"])
+    (tmp_path / "c.zkey").write_bytes(g["circuit.zkey"])
+    (tmp_path / "w.wtns").write_bytes(g["witness.wtns"])
+    _, w = g16.read_wtns(g["witness.wtns"])
+    (tmp_path / "bad.wtns").write_bytes(g16.write_wtns(w + [1]))
+    for mode in ("always", "0"):
+        env = dict(os.environ, ZKPOA_R=rs["r"], ZKPOA_S=rs["s"], ZKPOA_DETACH_EXIT=mode, ZKPOA_VERBOSE="1")
+        out = [str(tmp_path / ("proof_%s.json" % mode)), str(tmp_path / ("public_%s.json" % mode))]
+        rc = subprocess.run([zk.PROVER_BIN, str(tmp_path / "c.zkey"), str(tmp_path / "w.wtns")] + out, env=env,
+                            capture_output=True, text=True, timeout=120)
+        assert rc.returncode == 0, rc.stderr
+        assert open(out[0]).read() == g["proof_rapidsnark.json"] and open(out[1]).read() == g["public_rapidsnark.json"]
+        assert ("worker process" in rc.stderr) == (mode == "always")
+        bad = [str(tmp_path / ("nope_%s.json" % mode)), str(tmp_path / ("nopub_%s.json" % mode))]
+        rc = subprocess.run([zk.PROVER_BIN, str(tmp_path / "c.zkey"), str(tmp_path / "bad.wtns")] + bad, env=env,
+                            capture_output=True, text=True, timeout=120)
+        assert rc.returncode != 0 and "Invalid witness length" in rc.stderr
+        assert not os.path.exists(bad[0]) and not os.path.exists(bad[1])
+
+
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0", "0,0,0,0,0,0,0,0"])
 @pytest.mark.parametrize("tag", ["n8", "n128"])
 def test_prover_cli_one_proof_over_several_ranks(zk, tmp_path, devices, tag):

@@ -30,10 +30,19 @@ SHAPES = {"16": (16, 60000, 2), "21": (21, 2083343, 1), "25": (25, 21356921, 2),
 
 def run_cli(z, paths, env, tag):
     t0 = time.perf_counter()
+    m0 = time.monotonic() * 1e3
     rc = subprocess.run([z.PROVER_BIN] + paths, env=env, capture_output=True, text=True)
+    m1 = time.monotonic() * 1e3
     dt = time.perf_counter() - t0
     lines = [l for l in rc.stderr.strip().splitlines() if "WARNING" not in l and "amdgpu.ids" not in l]
-    return {"what": tag, "wall_s": dt, "rc": rc.returncode, "stderr": lines}
+    rec = {"what": tag, "wall_s": dt, "rc": rc.returncode, "stderr": lines}
+    for l in lines:   # the process's own stamps (same clock): what the caller waited for before main and after it
+        if "main entered at" in l:
+            a, b = l.split("main entered at")[1].split(", leaving at")
+            rec["before_main_ms"] = float(a) - m0
+            rec["after_main_ms"] = m1 - float(b.split(")")[0])
+            rec["worker_process"] = "worker process" in l
+    return rec
 
 
 def settle(gb):
