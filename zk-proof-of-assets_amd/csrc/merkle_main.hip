@@ -377,7 +377,9 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Error: %s\n", e.what());
     rc = 1;
   }
-  if (tree) zkpoa_merkle_free(ctx, tree);
-  if (ctx) zkpoa_context_destroy(ctx);
-  return rc;
+  // Both files are complete and renamed into place (or the error is on stderr): leave without the HIP runtime's
+  // teardown, as `prover` does -- freeing the tree and the context's queues is ~0.1 s a one-shot command never gets back
+  fflush(stdout);
+  fflush(stderr);
+  _exit(rc);
 }
