@@ -21,6 +21,7 @@
 
 #include <exception>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -142,7 +143,18 @@ static void parse_row(const char* b, const char* e, uint64_t* addr, uint64_t* ba
   memcpy(addr, av.v, 32);
   memcpy(bal, bv.v, 32);
 }
-static void read_anonymity_set(const std::string& path, std::vector<uint64_t>& addr, std::vector<uint64_t>& bal) {
+// rows x 4 limbs, NOT zero-filled: at 10 M rows the 640 MB would be touched once by one thread just to be overwritten --
+// the parsing threads are the first to touch their own part
+struct Limbs {
+  std::unique_ptr<uint64_t[]> p;
+  uint64_t rows = 0;
+  void alloc(uint64_t n) {
+    p.reset(new uint64_t[4 * (n ? n : 1)]);
+    rows = n;
+  }
+  uint64_t* data() { return p.get(); }
+};
+static void read_anonymity_set(const std::string& path, Limbs& addr, Limbs& bal) {
   int fd = open(path.c_str(), O_RDONLY);
   struct stat sb;
   if (fd < 0 || fstat(fd, &sb) != 0) {
@@ -216,12 +228,12 @@ static void read_anonymity_set(const std::string& path, std::vector<uint64_t>& a
     run([&](unsigned t) { for_lines(cut[t], cut[t + 1], [&](const char*, const char*) { rows[t]++; }); });
     std::vector<uint64_t> first(T + 1, 0);
     for (unsigned t = 0; t < T; t++) first[t + 1] = first[t] + rows[t];
-    addr.assign(4 * first[T], 0);
-    bal.assign(4 * first[T], 0);
+    addr.alloc(first[T]);
+    bal.alloc(first[T]);
     run([&](unsigned t) {
       uint64_t r = first[t];
       for_lines(cut[t], cut[t + 1], [&](const char* b, const char* e) {
-        parse_row(b, e, &addr[4 * r], &bal[4 * r]);
+        parse_row(b, e, addr.data() + 4 * r, bal.data() + 4 * r);
         r++;
       });
     });
@@ -280,7 +292,7 @@ int main(int argc, char** argv) {
     }
     int ctx_rc = PROVER_OK;
     std::thread ctx_thread([&] { ctx_rc = zkpoa_context_create((int)dev, &ctx, err, sizeof(err)); });
-    std::vector<uint64_t> addr, bal;
+    Limbs addr, bal;
     const double t0 = now_s();
     try {
       read_anonymity_set(anon, addr, bal);
@@ -290,7 +302,7 @@ int main(int argc, char** argv) {
     }
     const double t_read = now_s();
     ctx_thread.join();
-    const uint64_t n = addr.size() / 4;
+    const uint64_t n = addr.rows;
     if (n == 0) throw std::runtime_error("the anonymity set is empty");
     printf("Converting lines in '\"%s\"' into leaf nodes.. (leaf node = hash(address, balance))\n", anon.c_str());
     if (ctx_rc != PROVER_OK) throw std::runtime_error(err);
