@@ -89,11 +89,6 @@ static U256 parse_num(const std::string& s, unsigned base, const char* what) {
   return parse_num(s.data(), s.data() + s.size(), base, what);
 }
 
-static std::string trim(const std::string& s) {
-  size_t a = s.find_first_not_of(" \t\r\n\""), b = s.find_last_not_of(" \t\r\n\"");
-  return a == std::string::npos ? "" : s.substr(a, b - a + 1);
-}
-
 static std::string read_file(const std::string& path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("cannot open " + path);

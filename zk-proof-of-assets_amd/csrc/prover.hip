@@ -1653,7 +1653,6 @@ int emit(const std::string& s, char* buffer, unsigned long* size) {
   return PROVER_OK;
 }
 
-std::mutex g_ctx_mutex;
 zkpoa_context* g_ctx = nullptr;
 std::mutex g_prove_mutex;   // one-shot entry points share the process-wide context: one proof at a time
 // The file entry point is entered by several threads of a resident server. Two stages, two locks: g_stage_mutex covers
