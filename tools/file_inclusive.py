@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SHAPES = {"16": (16, 60000, 2), "21": (21, 2083343, 1), "25": (25, 21356921, 2), "26_l3": (26, 52367163, 13),
-          "26": (26, 61197000, 1), "27_l3": (27, 100845225, 13)}
+          "26": (26, 61197000, 1), "27_l3": (27, 100845225, 13), "28_l3": (28, 197801349, 13)}
 
 
 def run_cli(z, paths, env, tag):

@@ -1430,6 +1430,23 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
                                                          ", witness: " + std::to_string(w.n));
   zk->set_full();
   const uint64_t m = zk->nVars, n = zk->domain, nC = m - zk->nPublic - 1;
+  {
+    // What the overlapped form holds at its peak: the sections AND the compacted copies of the A / B queries (a hipFree
+    // would wait for the whole device, so the originals are only given back after the proof), the coefficient records
+    // AND their CSR form, the chain's work area, the witness -- plus the lanes' workspaces. A key for which that leaves
+    // the lanes less than a quarter of the card (2^28: 247 of 309 GB; 2^27: 125) is loaded first and proved afterwards (the caller's
+    // sequential path: temporaries freed as it goes, then the lanes' HBM budget of prove_partials).
+    size_t free_b = 0, total_b = 0;
+    ZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double peak = (double)n * 64 + (double)m * (64 + 128 + 64) + (double)nC * 64 + (double)m * 32 +
+                        (double)zk->nCoefs * (44 + 36) + (double)n * (8 + 96) + (double)m * (108 + 236);
+    if (peak > 0.72 * (double)total_b || peak > 0.8 * (double)free_b) {
+      if (req_getenv("ZKPOA_VERBOSE"))
+        fprintf(stderr, "zkpoa: the overlapped load would hold %.0f GB at its peak (%.0f GB free of %.0f): loading the key first\n",
+                peak / 1e9, free_b / 1e9, total_b / 1e9);
+      return nullptr;
+    }
+  }
   zkpoa_zkey* k = zk.get();
   void* d_recs = nullptr;
   uint32_t* d_cflag = nullptr;
