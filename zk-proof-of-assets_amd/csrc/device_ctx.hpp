@@ -43,11 +43,21 @@ struct Arena {
   size_t cap = 0;
   size_t off = 0;
   size_t limit = 0;   // 0 = whatever HBM holds; else reserve() refuses more than this (option lane_workspace_max_mb)
+  // bytes of HBM a key that is still being loaded will ask for (a staged one-shot prove: its lanes start while the
+  // sections are still arriving): a workspace may not take them
+  const std::atomic<int64_t>* hold_back = nullptr;
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
     if (limit && bytes > limit)
       throw OomError("workspace of " + std::to_string(bytes >> 20) + " MiB is over the lane limit of " +
                      std::to_string(limit >> 20) + " MiB");
+    if (hold_back) {
+      const int64_t keep = hold_back->load();
+      size_t free_b = 0, total_b = 0;
+      if (keep > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b + (double)cap < (double)bytes + (double)keep)
+        throw OomError("workspace of " + std::to_string(bytes >> 20) + " MiB would take HBM the key still being loaded needs (" +
+                       std::to_string(keep >> 20) + " MiB to come, " + std::to_string(free_b >> 20) + " MiB free)");
+    }
     if (base) ZK_HIP(hipFree(base));
     base = nullptr;
     cap = off = 0;   // (a failed allocation below must not leave a capacity without memory behind it)

@@ -1447,6 +1447,17 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       return nullptr;
     }
   }
+  // What of that is still to be allocated while the lanes already reserve their workspaces: every part is taken off as
+  // it is allocated, and a lane that would eat into the rest halves its piece instead (Arena::reserve, msm_run).
+  struct HoldBack {
+    std::atomic<int64_t>& v;
+    explicit HoldBack(std::atomic<int64_t>& x, double bytes) : v(x) { v = (int64_t)bytes; }
+    void done(double bytes) {
+      if (v.fetch_sub((int64_t)bytes) - (int64_t)bytes < 0) v = 0;
+    }
+    ~HoldBack() { v = 0; }
+  } hold(ctx->key_hold_back, (double)n * 64 + (double)m * 256 + (double)nC * 64 + (double)zk->nCoefs * 36 +
+                               (double)n * (8 + 96) + (double)m * (108 + 236));
   zkpoa_zkey* k = zk.get();
   void* d_recs = nullptr;
   uint32_t* d_cflag = nullptr;
@@ -1496,7 +1507,10 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
         ZK_HIP(hipSetDevice(ctx->dev.device));
         for (; i < S_COUNT; i++) {
           if (cancel.load()) throw ProverError(PROVER_ERROR, "upload cancelled");
-          if (!*items[i].dst) ZK_HIP(hipMalloc(items[i].dst, items[i].bytes ? items[i].bytes : 1));
+          if (!*items[i].dst) {
+            ZK_HIP(hipMalloc(items[i].dst, items[i].bytes ? items[i].bytes : 1));
+            hold.done((double)items[i].bytes);
+          }
           if (items[i].bytes) {
             if (items[i].id == S_WIT && w.fd >= 0) {   // file-backed witness: pread into the pinned staging buffers
               std::vector<uint8_t> small;
@@ -1534,6 +1548,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       have[S_COEF].get();
       build_csr(ctx, k, d_recs, false, L[0].stream);
       ntt_prepare(ctx, L[0].stream, k->power);
+      hold.done((double)k->nCoefs * 36 + (double)n * (8 + 96));
       mark("CSR + NTT tables built, H-scalar chain starts");
     };
     stg.prep_H = [&, k] {
@@ -1546,6 +1561,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       have[S_A].get();
       range_check<FqParams>(L[1].stream, k->dA, m * 2, d_cflag);
       query_compact(ctx, k, k->qA, k->dA, nullptr, m, L[1].stream);
+      hold.done((double)m * 108);
       mark("A query compacted, A MSM starts");
     };
     stg.prep_B = [&, k] {
@@ -1555,6 +1571,7 @@ zkpoa_zkey* load_prove_staged(zkpoa_context* ctx, const uint8_t* buf, uint64_t s
       range_check<FqParams>(L[2].stream, k->dB1, m * 2, d_cflag);
       range_check<FqParams>(L[2].stream, k->dB2, m * 4, d_cflag);
       query_compact(ctx, k, k->qB, k->dB1, k->dB2, m, L[2].stream);
+      hold.done((double)m * 236);
       mark("B query compacted, B MSMs start");
     };
     stg.prep_C = [&, k] {

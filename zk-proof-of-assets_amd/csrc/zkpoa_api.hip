@@ -30,6 +30,7 @@ extern "C" int zkpoa_context_create(int device, zkpoa_context** out, char* error
     c->dev.after_copy_stream = [c, device](hipStream_t st) { c->uploader.prepare(device, st); };
     c->dev.after_lanes = [c, device] { c->uploader.add_streams(device); };
     c->dev.init(device);
+    for (auto& l : c->dev.lanes) l.ws.hold_back = &c->key_hold_back;
     // cap of every MSM lane's workspace (as option lane_workspace_max_mb): a card shared with other work
     if (const char* e = getenv("ZKPOA_LANE_WORKSPACE_MAX_MB")) {
       if (*e) {

@@ -57,6 +57,8 @@ struct zkpoa_context {
     }
     return true;
   }
+  // HBM the key of a staged one-shot prove has still to allocate (prover.hip load_prove_staged); the lanes' arenas read it
+  std::atomic<int64_t> key_hold_back{0};
   int opt_prove_serial = 0;      // measurement: run the stages of a prove one at a time (solo device times)
   // split chain: the witness copy of zkpoa_split_stage1 is enqueued on lane 0; the other lanes' MSMs wait for it
   hipEvent_t ev_witness = nullptr;
