@@ -1,6 +1,9 @@
 // Host driver shared by msm_g1.hip / msm_g2.hip: device MSM + host window combination.
 #pragma once
 #include "msm.hip.h"
+
+#include <chrono>
+#include <thread>
 #include "zkpoa_internal.hpp"
 
 namespace zkpoa {
@@ -18,6 +21,7 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
   XYZZ<HF> total = XYZZ<HF>::inf();
   float tot_ms = 0, acc_sum = 0;
   uint64_t done = 0, adds = 0;
+  uint32_t hold_waits = 0;
   do {
     // (read every time round: a failed reservation below lowers it)
     const uint64_t max_pts = ctx->msm_points_limit(lane_id);
@@ -34,7 +38,16 @@ void msm_run(zkpoa_context* ctx, int lane_id, const void* d_bases, const void* d
     } catch (const OomError& e) {
       // HBM is full (a 2^27 key beside five whole-MSM workspaces; another process on the card): the workspace is
       // proportional to the points sorted at once, so go through them in halves -- the sum is the same
-      if (!ctx->shrink_after_oom(lane_id, cnt)) throw;
+      if (!ctx->shrink_after_oom(lane_id, cnt)) {
+        // nothing smaller to try. If the refusal came from the hold-back of a key that is still being loaded (an upper
+        // bound), its last allocations are moments away: wait for them (bounded) before giving up
+        if (ctx->key_hold_back.load() > 0 && hold_waits < 5000) {
+          hold_waits++;
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+          continue;
+        }
+        throw;
+      }
       if (getenv("ZKPOA_VERBOSE"))
         fprintf(stderr, "zkpoa:   lane %d: %s for %llu points at once; continuing with at most %llu\n", lane_id, e.what(),
                 (unsigned long long)cnt, (unsigned long long)ctx->msm_points_limit(lane_id));
