@@ -309,6 +309,10 @@ int zkpoa_setup_accumulate(zkpoa_context* ctx, int group, const void* d_points, 
  * is not restated (nothing in the reference pins it), so the key proves and verifies but `snarkjs zkey verify` would
  * not accept its hash. The `zkpoa-setup` executable takes snarkjs' argument order. Errors: zkpoa_last_error. */
 int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path);
+/* For a one-shot command only (zkpoa-setup): on != 0 leaves the large host arrays of zkpoa_zkey_new to the process's
+ * exit instead of freeing them before the call returns (giving ~100 GB back page by page takes seconds at the
+ * layer-three shape). A long-lived caller leaves this off. */
+void zkpoa_setup_defer_host_frees(int on);
 /* The arithmetic of `snarkjs zkey contribute <in.zkey> <out.zkey>` (g16_setup.sh:262-266): with a secret d (delta_le:
  * 32 B little-endian in [1, r); NULL = drawn from /dev/urandom), delta1, delta2 <- d * delta1, d * delta2 and every
  * point of sections 8 (C) and 9 (H) <- (1/d) * point (device; one scalar for all points, so no lane diverges). All

@@ -98,6 +98,11 @@ if "--files" in sys.argv:
         for sid, payload in secs:
             f.write(struct.pack("<IQ", sid, len(payload))); f.write(payload)
     print("inputs written in %.1f s: r1cs %.2f GB, ptau %.2f GB" % (time.perf_counter() - t0, os.path.getsize(d + "/c.r1cs") / 1e9, os.path.getsize(d + "/pot.ptau") / 1e9))
+    # (at 2^26 the inputs are 62 GB and the two keys 69 GB, all in /dev/shm, i.e. in host memory: give back what this
+    # script itself still holds -- the box allows one command 270 GB)
+    del secs, body, rec, a, b, dd, e
+    import gc; gc.collect()
+    g1 = g2 = None; torch.cuda.empty_cache()
     for i in range(2):
         t0 = time.perf_counter()
         rc = subprocess.run([z.SETUP_BIN, "zkey", "new", d + "/c.r1cs", d + "/pot.ptau", d + "/c_0.zkey"], capture_output=True, text=True, env=dict(os.environ, ZKPOA_VERBOSE="1"))

@@ -41,7 +41,7 @@ EXPORTS = [
     "zkpoa_msm_g1_device_lane", "zkpoa_last_ms_lane",
     "zkpoa_gen_bases_g1_device", "zkpoa_gen_bases_g2_device",
     "zkpoa_g1_sum", "zkpoa_g2_sum", "zkpoa_g1_mul", "zkpoa_g2_mul",
-    "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_msm_points_limit", "zkpoa_field_op", "zkpoa_group_add",
+    "zkpoa_setup_defer_host_frees", "zkpoa_last_ms", "zkpoa_set_option", "zkpoa_msm_points_limit", "zkpoa_field_op", "zkpoa_group_add",
     "zkpoa_groth16_verify", "zkpoa_sanitize_proof", "zkpoa_groth16_verify_points", "zkpoa_zkey_vkey", "zkpoa_zkey_export_vkey",
     "zkpoa_zkey_read_h_scalars", "zkpoa_zkey_precompute",
     "zkpoa_context_stream", "zkpoa_context_synchronize",

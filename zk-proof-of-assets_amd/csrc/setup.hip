@@ -31,8 +31,12 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
 #include <map>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace zkpoa;
@@ -375,6 +379,73 @@ struct MappedFile {
 // Output files are written under a temporary name and renamed into place (as prover_main's write_atomic): a failure
 // part-way (ENOSPC, HIP error, kill) never leaves a truncated .zkey under the final name for a later "skip if the zkey
 // exists" step to pick up, and writing over the input of `zkey contribute` is safe (the mapping keeps the old inode).
+// ---- host-side parallelism (r04) ---------------------------------------------------------------------------------------
+// At the layer-three shape `zkey new` reads 62 GB and writes 35 GB, and the device's share of the command is 3.5 s: what
+// was left was one host thread parsing, copying and converting (54 s in all). Every host stage below is split over
+// the host's threads; the arrays they fill are not zero-filled first (UVec), the threads are the first to touch them.
+unsigned host_threads() {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* e = getenv("ZKPOA_SETUP_THREADS")) {
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end != e && !*end && v >= 1 && v <= 256) t = (unsigned)v;
+  }
+  return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+// fn(t, lo, hi) over [0, count) cut into host_threads() ranges; the first exception (in range order) is rethrown
+template <class Fn>
+void parallel_ranges(uint64_t count, uint64_t min_per_thread, Fn fn) {
+  unsigned T = host_threads();
+  if (count / (min_per_thread ? min_per_thread : 1) < T) T = (unsigned)(count / (min_per_thread ? min_per_thread : 1));
+  if (T <= 1) {
+    fn(0u, (uint64_t)0, count);
+    return;
+  }
+  std::vector<std::exception_ptr> errs(T);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; t++)
+    th.emplace_back([&, t] {
+      try {
+        fn(t, count * t / T, count * (t + 1) / T);
+      } catch (...) {
+        errs[t] = std::current_exception();
+      }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+// One-shot commands (zkpoa-setup) leave the tens of GB of host arrays of a `zkey new` to the process's exit: giving
+// 100 GB back page by page takes seconds that nobody is waiting for any more (zkpoa_setup_defer_host_frees).
+std::atomic<bool>& defer_host_frees() {
+  static std::atomic<bool> on{false};
+  return on;
+}
+template <class T>
+struct UVec {   // a sized array of trivially copyable elements whose storage is NOT value-initialised
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  UVec() = default;
+  UVec(UVec&&) = default;
+  UVec& operator=(UVec&&) = default;
+  ~UVec() {
+    if (defer_host_frees().load()) (void)p.release();
+  }
+  explicit UVec(size_t count) { alloc(count); }
+  void alloc(size_t count) {
+    p.reset(new T[count ? count : 1]);
+    n = count;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T* data() { return p.get(); }
+  const T* data() const { return p.get(); }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  const T* begin() const { return p.get(); }
+  const T* end() const { return p.get() + n; }
+};
+
 struct AtomicFile {
   std::string path, tmp;
   FILE* f = nullptr;
@@ -385,6 +456,33 @@ struct AtomicFile {
   }
   void write(const void* p, size_t len) {
     if (ok && len) ok = fwrite(p, 1, len, f) == len;
+  }
+  // a payload of GBs: the stream is flushed, the file extended, and the bytes are copied by several threads through a
+  // shared mapping of their final place (buffered write() calls to one file queue up behind its inode lock -- measured on
+  // tmpfs: eight pwrite threads were no faster than one fwrite); the stream then continues behind them
+  void write_large(const void* p, size_t len) {
+    if (len < (64u << 20)) return write(p, len);
+    if (!ok) return;
+    if (fflush(f) != 0) {
+      ok = false;
+      return;
+    }
+    const off_t base = ftello(f);
+    const int fd = fileno(f);
+    if (base < 0 || ftruncate(fd, base + (off_t)len) != 0) {
+      ok = false;
+      return;
+    }
+    const off_t map_off = base & ~(off_t)4095;
+    const size_t lead = (size_t)(base - map_off);
+    void* m = mmap(nullptr, lead + len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, map_off);
+    if (m == MAP_FAILED) {   // a file system without shared mappings: the plain way
+      ok = fseeko(f, base, SEEK_SET) == 0;
+      return write(p, len);
+    }
+    char* dst = static_cast<char*>(m) + lead;
+    parallel_ranges(len, 32ull << 20, [&](unsigned, uint64_t lo, uint64_t hi) { memcpy(dst + lo, static_cast<const char*>(p) + lo, hi - lo); });
+    ok = munmap(m, lead + len) == 0 && fseeko(f, base + (off_t)len, SEEK_SET) == 0;
   }
   void commit() {
     ok = (fclose(f) == 0) && ok;
@@ -407,11 +505,13 @@ struct AtomicFile {
 // Untrusted inputs: the device keeps Fq elements lazily in [0, 2q) and takes file bytes raw, so every
 // coordinate that reaches a kernel or is copied into the key must be a canonical field element (< q).
 void host_check_coords(const uint8_t* p, uint64_t count32, const char* what) {
-  for (uint64_t i = 0; i < count32; i++) {
-    uint64_t v[4];
-    memcpy(v, p + 32 * i, 32);
-    if (v[3] >= HFqParams::P[3] && HFq::geq_p(v)) throw SetupError(std::string(what) + ": a coordinate is not a field element (>= q)");
-  }
+  parallel_ranges(count32, 1u << 20, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      uint64_t v[4];
+      memcpy(v, p + 32 * i, 32);
+      if (v[3] >= HFqParams::P[3] && HFq::geq_p(v)) throw SetupError(std::string(what) + ": a coordinate is not a field element (>= q)");
+    }
+  });
 }
 void dev_check_coords(zkpoa_context* ctx, const void* d, uint64_t count32, const char* what) {
   if (!count32) return;
@@ -458,9 +558,12 @@ struct Term {
 
 struct R1cs {
   uint32_t nWires = 0, nPublic = 0, nConstraints = 0;
-  std::vector<Term> A, B, C;   // per constraint in file order, terms of one linear combination ascending by signal
+  UVec<Term> A, B, C;   // per constraint in file order, terms of one linear combination ascending by signal
 };
 
+// Two passes: the first walks the term counts only (three words per constraint) and notes, every 2^14 constraints, where
+// the constraint starts in the file and how many A / B / C terms precede it; the second parses those blocks in parallel
+// straight into their places.
 R1cs parse_r1cs(const MappedFile& f) {
   auto secs = bin_sections(f, "r1cs", 1, "r1cs");
   if (!secs.count(1) || !secs.count(2)) throw SetupError("r1cs: header or constraint section missing");
@@ -475,45 +578,71 @@ R1cs parse_r1cs(const MappedFile& f) {
   r.nConstraints = rd32(q + 24);
   if (r.nWires == 0 || n_public + 1 > r.nWires) throw SetupError("r1cs: inconsistent wire counts");
   r.nPublic = (uint32_t)n_public;
-  uint64_t pos = cs.off;
   const uint64_t end = cs.off + cs.len;
-  std::vector<Term> lc;
-  for (uint32_t c = 0; c < r.nConstraints; c++) {
-    for (int m = 0; m < 3; m++) {
-      if (pos + 4 > end) throw SetupError("r1cs: constraint section truncated");
-      const uint32_t nt = rd32(f.p + pos);
-      pos += 4;
-      if ((uint64_t)nt * 36 > end - pos) throw SetupError("r1cs: constraint section truncated");
-      lc.clear();
-      for (uint32_t t = 0; t < nt; t++, pos += 36) {
-        Term x;
-        x.c = c;
-        x.s = rd32(f.p + pos);
-        memcpy(x.coef, f.p + pos + 4, 32);
-        if (x.s >= r.nWires) throw SetupError("r1cs: wire index out of range");
-        uint64_t v[4];
-        memcpy(v, x.coef, 32);
-        if (HFr::geq_p(v)) throw SetupError("r1cs: coefficient is not a field element (>= r)");
-        lc.push_back(x);
+  constexpr uint32_t kBlock = 1u << 14;
+  struct Mark { uint64_t pos, cnt[3]; };
+  std::vector<Mark> marks;
+  marks.reserve(r.nConstraints / kBlock + 2);
+  {
+    uint64_t pos = cs.off, cnt[3] = {0, 0, 0};
+    for (uint32_t c = 0; c < r.nConstraints; c++) {
+      if ((c & (kBlock - 1)) == 0) marks.push_back(Mark{pos, {cnt[0], cnt[1], cnt[2]}});
+      for (int m = 0; m < 3; m++) {
+        if (pos + 4 > end) throw SetupError("r1cs: constraint section truncated");
+        const uint32_t nt = rd32(f.p + pos);
+        pos += 4;
+        if ((uint64_t)nt * 36 > end - pos) throw SetupError("r1cs: constraint section truncated");
+        pos += (uint64_t)nt * 36;
+        cnt[m] += nt;
       }
-      // snarkjs holds a linear combination as an object keyed by the signal: iteration is ascending by signal
-      std::stable_sort(lc.begin(), lc.end(), [](const Term& a, const Term& b) { return a.s < b.s; });
-      for (size_t t = 1; t < lc.size(); t++)
-        if (lc[t].s == lc[t - 1].s) throw SetupError("r1cs: a signal occurs twice in one linear combination");
-      std::vector<Term>& dst = m == 0 ? r.A : (m == 1 ? r.B : r.C);
-      dst.insert(dst.end(), lc.begin(), lc.end());
     }
+    marks.push_back(Mark{pos, {cnt[0], cnt[1], cnt[2]}});
   }
+  const Mark& tot = marks.back();
+  r.A.alloc(tot.cnt[0]);
+  r.B.alloc(tot.cnt[1]);
+  r.C.alloc(tot.cnt[2]);
+  const uint64_t blocks = marks.size() - 1;
+  parallel_ranges(blocks, 1, [&](unsigned, uint64_t b0, uint64_t b1) {
+    for (uint64_t b = b0; b < b1; b++) {
+      uint64_t pos = marks[b].pos, at[3] = {marks[b].cnt[0], marks[b].cnt[1], marks[b].cnt[2]};
+      const uint32_t c1 = (uint32_t)std::min<uint64_t>((b + 1) * kBlock, r.nConstraints);
+      for (uint32_t c = (uint32_t)(b * kBlock); c < c1; c++) {
+        for (int m = 0; m < 3; m++) {
+          const uint32_t nt = rd32(f.p + pos);
+          pos += 4;
+          Term* dst = (m == 0 ? r.A.data() : (m == 1 ? r.B.data() : r.C.data())) + at[m];
+          for (uint32_t t = 0; t < nt; t++, pos += 36) {
+            Term& x = dst[t];
+            x.c = c;
+            x.s = rd32(f.p + pos);
+            memcpy(x.coef, f.p + pos + 4, 32);
+            if (x.s >= r.nWires) throw SetupError("r1cs: wire index out of range");
+            uint64_t v[4];
+            memcpy(v, x.coef, 32);
+            if (HFr::geq_p(v)) throw SetupError("r1cs: coefficient is not a field element (>= r)");
+          }
+          // snarkjs holds a linear combination as an object keyed by the signal: iteration is ascending by signal
+          std::stable_sort(dst, dst + nt, [](const Term& a, const Term& b) { return a.s < b.s; });
+          for (uint32_t t = 1; t < nt; t++)
+            if (dst[t].s == dst[t - 1].s) throw SetupError("r1cs: a signal occurs twice in one linear combination");
+          at[m] += nt;
+        }
+      }
+    }
+  });
   return r;
 }
 
 void pread_all(int fd, void* dst, uint64_t len, uint64_t off, const char* what) {
-  uint64_t got = 0;
-  while (got < len) {
-    ssize_t n = pread(fd, static_cast<char*>(dst) + got, len - got, (off_t)(off + got));
-    if (n <= 0) throw SetupError(std::string("ptau: short read of ") + what);
-    got += (uint64_t)n;
-  }
+  parallel_ranges(len, 32ull << 20, [&](unsigned, uint64_t lo, uint64_t hi) {
+    uint64_t got = lo;
+    while (got < hi) {
+      ssize_t n = pread(fd, static_cast<char*>(dst) + got, hi - got, (off_t)(off + got));
+      if (n <= 0) throw SetupError(std::string("ptau: short read of ") + what);
+      got += (uint64_t)n;
+    }
+  });
 }
 
 struct DevArr {
@@ -527,24 +656,29 @@ struct DevArr {
   }
 };
 
-struct Entries {   // one zkpoa_setup_accumulate call
-  std::vector<uint8_t> coef;
-  std::vector<uint32_t> pidx, sig;
-  void add(const Term& t, uint32_t point_offset) {
-    coef.insert(coef.end(), t.coef, t.coef + 32);
-    pidx.push_back(point_offset + t.c);
-    sig.push_back(t.s);
+struct Entries {   // one zkpoa_setup_accumulate call; filled in place by several threads (set)
+  UVec<uint8_t> coef;
+  UVec<uint32_t> pidx, sig;
+  void alloc(uint64_t count) {
+    coef.alloc(count * 32);
+    pidx.alloc(count);
+    sig.alloc(count);
   }
-  void add_one(uint32_t point, uint32_t signal) {
-    uint8_t one[32] = {1};
-    coef.insert(coef.end(), one, one + 32);
-    pidx.push_back(point);
-    sig.push_back(signal);
+  void set(uint64_t i, const Term& t, uint32_t point_offset) {
+    memcpy(&coef[i * 32], t.coef, 32);
+    pidx[i] = point_offset + t.c;
+    sig[i] = t.s;
+  }
+  void set_one(uint64_t i, uint32_t point, uint32_t signal) {
+    memset(&coef[i * 32], 0, 32);
+    coef[i * 32] = 1;
+    pidx[i] = point;
+    sig[i] = signal;
   }
 };
 
 template <class F>
-std::vector<uint8_t> run_accumulate(zkpoa_context* ctx, const DevArr& points, uint64_t n_points, const Entries& e,
+UVec<uint8_t> run_accumulate(zkpoa_context* ctx, const DevArr& points, uint64_t n_points, const Entries& e,
                                     uint64_t n_signals) {
   constexpr size_t A = MsmSizes<F>::kAffine;
   const uint64_t nnz = e.sig.size();
@@ -553,7 +687,7 @@ std::vector<uint8_t> run_accumulate(zkpoa_context* ctx, const DevArr& points, ui
   pidx.up(e.pidx.data(), nnz * 4);
   sig.up(e.sig.data(), nnz * 4);
   setup_accumulate<F>(ctx, points.p, n_points, coef.p, (const uint32_t*)pidx.p, (const uint32_t*)sig.p, nnz, n_signals, out.p);
-  std::vector<uint8_t> host(n_signals * A);
+  UVec<uint8_t> host(n_signals * A);
   if (!host.empty()) ZK_HIP(hipMemcpy(host.data(), out.p, host.size(), hipMemcpyDeviceToHost));
   return host;
 }
@@ -596,7 +730,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     if (off + count * unit > ps[sec].len) throw SetupError(std::string("ptau: section too short for ") + what);
     return ps[sec].off + off;
   };
-  std::vector<uint8_t> L1(n * 64), L2(n * 128), aL(n * 64), bL(n * 64), Hs(2 * n * 64);
+  UVec<uint8_t> L1(n * 64), L2(n * 128), aL(n * 64), bL(n * 64), Hs(2 * n * 64);
   pread_all(fp.fd, L1.data(), L1.size(), level(12, cp, 64, n, "tau*G1 (Lagrange)"), "tau*G1 (Lagrange)");
   pread_all(fp.fd, L2.data(), L2.size(), level(13, cp, 128, n, "tau*G2 (Lagrange)"), "tau*G2 (Lagrange)");
   pread_all(fp.fd, aL.data(), aL.size(), level(14, cp, 64, n, "alpha*tau*G1 (Lagrange)"), "alpha*tau*G1 (Lagrange)");
@@ -615,16 +749,32 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
 
   // entries of the three accumulations (+ the nPublic + 1 rows `1 * signal_i` that bind the public inputs)
   Entries eA, eB, eK;
-  for (const Term& t : r.A) { eA.add(t, 0); eK.add(t, 0); }                      // K: A over beta*L  (points [0, n))
-  for (const Term& t : r.B) { eB.add(t, 0); eK.add(t, (uint32_t)n); }            //    B over alpha*L ([n, 2n))
-  for (const Term& t : r.C) eK.add(t, (uint32_t)(2 * n));                         //    C over L       ([2n, 3n))
+  const uint64_t nA = r.A.size(), nB = r.B.size(), nCt = r.C.size(), nPub1 = (uint64_t)r.nPublic + 1;
+  eA.alloc(nA + nPub1);
+  eB.alloc(nB);
+  eK.alloc(nA + nB + nCt + nPub1);
+  parallel_ranges(nA, 1u << 16, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      eA.set(i, r.A[i], 0);
+      eK.set(i, r.A[i], 0);                                      // K: A over beta*L  (points [0, n))
+    }
+  });
+  parallel_ranges(nB, 1u << 16, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      eB.set(i, r.B[i], 0);
+      eK.set(nA + i, r.B[i], (uint32_t)n);                       //    B over alpha*L ([n, 2n))
+    }
+  });
+  parallel_ranges(nCt, 1u << 16, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) eK.set(nA + nB + i, r.C[i], (uint32_t)(2 * n));   //    C over L       ([2n, 3n))
+  });
   for (uint32_t i = 0; i <= r.nPublic; i++) {
-    eA.add_one(r.nConstraints + i, i);
-    eK.add_one(r.nConstraints + i, i);
+    eA.set_one(nA + i, r.nConstraints + i, i);
+    eK.set_one(nA + nB + nCt + i, r.nConstraints + i, i);
   }
   phase("entry lists built");
   const uint64_t m = r.nWires;
-  std::vector<uint8_t> secA, secB1, secB2, secK;
+  UVec<uint8_t> secA, secB1, secB2, secK;
   {
     DevArr dL1(n * 64);
     dL1.up(L1.data(), L1.size());
@@ -649,7 +799,8 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
 
   phase("point sections (upload, device, download)");
   // ---- the file: sections 1-10 in the order snarkjs numbers them
-  std::vector<uint8_t> s2, s4, s9(n * 64), s10(64 + 4, 0);
+  std::vector<uint8_t> s2, s10(64 + 4, 0);
+  UVec<uint8_t> s4, s9(n * 64);
   put32(s2, 32);
   s2.insert(s2.end(), (const uint8_t*)HFqParams::P, (const uint8_t*)HFqParams::P + 32);
   put32(s2, 32);
@@ -669,27 +820,41 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   // coefficients: A and B terms per constraint, then the public rows; values scaled by R^2
   const uint64_t nCoefs = r.A.size() + r.B.size() + r.nPublic + 1;
   if (nCoefs > 0xffffffffull) throw SetupError("more than 2^32 coefficients");
-  put32(s4, (uint32_t)nCoefs);
-  s4.reserve(4 + nCoefs * 44);
-  auto rec = [&](uint32_t mtx, uint32_t c, uint32_t sgn, const uint8_t* coef) {
-    put32(s4, mtx);
-    put32(s4, c);
-    put32(s4, sgn);
+  s4.alloc(4 + nCoefs * 44);
+  {
+    const uint32_t nc32 = (uint32_t)nCoefs;
+    memcpy(s4.data(), &nc32, 4);
+  }
+  auto rec = [&](uint64_t at, uint32_t mtx, uint32_t c, uint32_t sgn, const uint8_t* coef) {
+    uint8_t* o = s4.data() + 4 + at * 44;
+    memcpy(o, &mtx, 4);
+    memcpy(o + 4, &c, 4);
+    memcpy(o + 8, &sgn, 4);
     HFr v = HFr::from_bytes(coef).to_mont();   // limbs = coef * R
     HFr w = v.to_mont();                       // limbs = coef * R^2
-    s4.insert(s4.end(), (const uint8_t*)w.l, (const uint8_t*)w.l + 32);
+    memcpy(o + 12, w.l, 32);
   };
-  {
-    size_t ia = 0, ib = 0;
-    for (uint32_t c = 0; c < r.nConstraints; c++) {
-      for (; ia < r.A.size() && r.A[ia].c == c; ia++) rec(0, c, r.A[ia].s, r.A[ia].coef);
-      for (; ib < r.B.size() && r.B[ib].c == c; ib++) rec(1, c, r.B[ib].s, r.B[ib].coef);
+  // constraint ranges in parallel: a range starts at the first A / B term of its first constraint, and its records
+  // start at the count of A and B terms before that
+  parallel_ranges(r.nConstraints, 1u << 14, [&](unsigned, uint64_t c0, uint64_t c1) {
+    auto first = [&](const UVec<Term>& v, uint32_t c) {
+      return (size_t)(std::lower_bound(v.begin(), v.end(), c, [](const Term& t, uint32_t key) { return t.c < key; }) - v.begin());
+    };
+    size_t ia = first(r.A, (uint32_t)c0), ib = first(r.B, (uint32_t)c0);
+    uint64_t at = ia + ib;
+    for (uint32_t c = (uint32_t)c0; c < (uint32_t)c1; c++) {
+      for (; ia < r.A.size() && r.A[ia].c == c; ia++) rec(at++, 0, c, r.A[ia].s, r.A[ia].coef);
+      for (; ib < r.B.size() && r.B[ib].c == c; ib++) rec(at++, 1, c, r.B[ib].s, r.B[ib].coef);
     }
+  });
+  {
     const uint8_t one[32] = {1};
-    for (uint32_t i = 0; i <= r.nPublic; i++) rec(0, r.nConstraints + i, i, one);
+    for (uint32_t i = 0; i <= r.nPublic; i++) rec(r.A.size() + r.B.size() + i, 0, r.nConstraints + i, i, one);
   }
   phase("coefficient section");
-  for (uint64_t i = 0; i < n; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
+  parallel_ranges(n, 1u << 18, [&](unsigned, uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
+  });
   const size_t icb = ((size_t)r.nPublic + 1) * 64;
   struct Out { uint32_t id; const uint8_t* p; uint64_t len; };
   const uint32_t one_u32 = 1;   // section 1: protocol id 1 = groth16
@@ -704,7 +869,7 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   for (const Out& o : outs) {
     fo.write(&o.id, 4);
     fo.write(&o.len, 8);
-    fo.write(o.p, o.len);
+    fo.write_large(o.p, o.len);
   }
   fo.commit();
   phase("zkey written");
@@ -732,7 +897,7 @@ uint64_t wtns_check(zkpoa_context* ctx, const char* r1cs_path, const char* wtns_
   std::vector<uint8_t> coef(nnz * 32);
   {
     size_t ia = 0, ib = 0, ic = 0, t = 0;
-    auto take = [&](const std::vector<Term>& v, size_t& i, uint32_t c) {
+    auto take = [&](const UVec<Term>& v, size_t& i, uint32_t c) {
       for (; i < v.size() && v[i].c == c; i++, t++) {
         sig[t] = v[i].s;
         memcpy(&coef[t * 32], v[i].coef, 32);
@@ -820,7 +985,7 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
     h_affine_to_bytes<HFq2>(h_to_affine(h_mul(XYZZ<HFq2>::from_affine(d2), dv)), &s2[kDelta2]);
   }
   auto scaled = [&](const Sec& sc) {
-    std::vector<uint8_t> out(sc.len);
+    UVec<uint8_t> out(sc.len);
     if (sc.len) {
       DevArr in(sc.len), res(sc.len);
       in.up(fi.p + sc.off, sc.len);
@@ -830,7 +995,7 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
     }
     return out;
   };
-  const std::vector<uint8_t> s8 = scaled(secs[8]), s9 = scaled(secs[9]);
+  const UVec<uint8_t> s8 = scaled(secs[8]), s9 = scaled(secs[9]);
   AtomicFile fo(out_path);   // temporary name + rename: in_path == out_path is fine (the mapping keeps the old inode)
   fo.write("zkey", 4);
   const uint32_t hdr[2] = {1, 10};
@@ -843,7 +1008,7 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
     if (t == 9) p = s9.data();
     fo.write(&t, 4);
     fo.write(&len, 8);
-    fo.write(p, len);
+    fo.write_large(p, len);
   }
   fo.commit();
 }
@@ -865,6 +1030,8 @@ extern "C" int zkpoa_zkey_contribute(zkpoa_context* ctx, const char* zkey_in_pat
   zkey_contribute(ctx, zkey_in_path, zkey_out_path, delta_le);
   ZK_API_END(ctx)
 }
+
+extern "C" void zkpoa_setup_defer_host_frees(int on) { defer_host_frees() = on != 0; }
 
 extern "C" int zkpoa_zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, const char* zkey_path) {
   ZK_API_BEGIN(ctx)
