@@ -13,6 +13,7 @@
 // keys in HBM (groth16_prover_zkey_file's cache, keyed by inode + size + mtime). `prover --stop-server` ends it.
 // The socket lives in a 0700 directory of the calling user and the server checks the peer's uid.
 #include "../../include/zkpoa_prover.h"
+#include "worker_exit.hpp"
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -617,84 +618,23 @@ int main(int argc, char** argv) {
     }
     // no server reachable: prove in this process (still on the GPU)
   }
-  // A large key: the proof is made by a worker process and this one leaves as soon as the worker reports that both
-  // outputs are in place. Even without the HIP runtime's own teardown (below) the kernel takes 130-165 ms to dismantle a
-  // process that holds a 13-30 GB key and its workspaces on the GPU (measured at the layer-two and layer-three shapes,
-  // tools/file_inclusive.py `after_main_ms`; 2 ms at layer one), and a caller that waits for the exit waits for that
-  // too. The worker keeps its GPU lock until it is gone, so the next prover on this GPU starts after it. Not under a
-  // preloaded profiler (it has loaded the GPU runtime into this process already: no fork after that); ZKPOA_DETACH_EXIT=0
-  // keeps everything in one process ("always": a worker for small keys too -- tests).
-  int report_fd = -1;
-  {
-    struct stat zs;
-    const char* det = getenv("ZKPOA_DETACH_EXIT");
-    const bool big = (det && strcmp(det, "always") == 0) || (stat(argv[1], &zs) == 0 && zs.st_size >= (2ll << 30));
-    int pfd[2];
-    // (a GPU runtime already in this process -- a preloaded profiler's -- rules the fork out: RTLD_NOLOAD only asks)
-    bool gpu_runtime_loaded = false;
-    for (const char* lib : {"libhsa-runtime64.so.1", "libhsa-runtime64.so", "libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"})
-      if (void* h = dlopen(lib, RTLD_NOLOAD | RTLD_LAZY)) {
-        gpu_runtime_loaded = true;
-        dlclose(h);
-      }
-    if (big && !(det && strcmp(det, "0") == 0) && !gpu_runtime_loaded && pipe2(pfd, O_CLOEXEC) == 0) {
-      fflush(stdout);
-      fflush(stderr);
-      const pid_t self = getpid();
-      const pid_t worker = fork();
-      if (worker < 0) {
-        close(pfd[0]);
-        close(pfd[1]);
-      } else if (worker > 0) {
-        close(pfd[1]);
-        unsigned char code = 0;
-        ssize_t got;
-        do got = read(pfd[0], &code, 1);
-        while (got < 0 && errno == EINTR);
-        if (got == 1) _exit(code);   // outputs complete, or the failure is on stderr: the worker's exit is not ours to wait for
-        int st = 0;                  // the worker ended without a report
-        while (waitpid(worker, &st, 0) < 0 && errno == EINTR) {
-        }
-        if (WIFEXITED(st) && WEXITSTATUS(st) != 0) return WEXITSTATUS(st);
-        fprintf(stderr, "prover: the worker process ended abnormally (%s %d)\n", WIFSIGNALED(st) ? "signal" : "status",
-                WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
-        return EXIT_FAILURE;
-      } else {
-        close(pfd[0]);
-        report_fd = pfd[1];
-        prctl(PR_SET_PDEATHSIG, SIGKILL);   // killing the prover kills the proof, as in one process
-        if (getppid() != self) _exit(EXIT_FAILURE);   // (the parent went away before the line above took effect)
-      }
-    }
-  }
-  auto report = [&](int code) {   // worker: hand the exit status over, then stop holding the caller's pipes open
-    if (report_fd < 0) return;
-    fflush(stdout);
-    fflush(stderr);
-    const unsigned char b = (unsigned char)code;
-    (void)!write(report_fd, &b, 1);
-    close(report_fd);
-    close(STDIN_FILENO);
-    close(STDOUT_FILENO);
-    close(STDERR_FILENO);
-  };
+  // A key of 2 GB or more: the proof is made by a worker process and this one leaves as soon as both outputs are in
+  // place (csrc/worker_exit.hpp).
+  struct stat zs;
+  zkpoa::WorkerExit we = zkpoa::WorkerExit::start(stat(argv[1], &zs) == 0 && zs.st_size >= (2ll << 30), "prover");
   std::string message;
   bool runtime_failure = false;
   int rc = prove_files(argv[1], argv[2], argv[3], argv[4], message, &runtime_failure);
   if (rc != EXIT_SUCCESS) {
     fprintf(stderr, "%s\n", message.c_str());
     if (runtime_failure) log_fault("in-process prove hit a HIP runtime failure", message, argv[1]);
-    report(rc);
-    if (report_fd >= 0) _exit(rc);
+    if (we.is_worker()) we.leave(rc);
     return rc;
   }
   if (getenv("ZKPOA_VERBOSE"))   // (CLOCK_MONOTONIC stamps: a caller can see what it waited for before main and after it)
     fprintf(stderr, "zkpoa: prover process total %.1f ms (main entered at %.1f, leaving at %.1f)%s\n", now_ms() - t_start, t_start,
-            now_ms(), report_fd >= 0 ? "; worker process, the caller is released now" : "");
+            now_ms(), we.is_worker() ? "; worker process, the caller is released now" : "");
   // Both outputs are complete and renamed into place: leave without running the HIP runtime's teardown
   // (freeing tens of GB of device memory and its queues costs ~0.25 s that a one-shot prover never gets back).
-  fflush(stdout);
-  fflush(stderr);
-  report(EXIT_SUCCESS);
-  _exit(EXIT_SUCCESS);
+  we.leave(EXIT_SUCCESS);
 }

@@ -8,16 +8,12 @@
 // prepare phase2`), as snarkjs requires too. Exit status 0 / non-zero + message on stderr.
 #include "../../include/zkpoa_prover.h"
 
-#include <errno.h>
-#include <fcntl.h>
-#include <signal.h>
+#include "worker_exit.hpp"
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/prctl.h>
-#include <sys/wait.h>
 #include <time.h>
-#include <unistd.h>
 
 static bool parse_decimal_or_hex(const char* s, uint8_t out[32]) {   // ZKPOA_DELTA: decimal, or 0x... hex; < 2^256
   memset(out, 0, 32);
@@ -78,55 +74,13 @@ int main(int argc, char** argv) {
     fprintf(stderr, "zkpoa-setup: WARNING: delta taken from ZKPOA_DELTA -- whoever knows it can forge proofs for this key\n");
     delta_p = delta;
   }
-  // `zkey new` / `zkey contribute` run in a worker process and this one leaves as soon as the worker reports that the
-  // key is renamed into place: a worker that has held ~100 GB of host arrays and a context on the GPU takes seconds to
-  // be dismantled by the kernel (layer-three shape), which nobody needs to wait for. Same arrangement as `prover`'s
-  // (csrc/prover_main.hip); ZKPOA_DETACH_EXIT=0 keeps one process. Forked before anything touches the GPU.
-  int report_fd = -1;
-  {
-    const char* det = getenv("ZKPOA_DETACH_EXIT");
-    int pfd[2];
-    if (!check && !(det && strcmp(det, "0") == 0) && pipe2(pfd, O_CLOEXEC) == 0) {
-      fflush(stdout);
-      fflush(stderr);
-      const pid_t self = getpid();
-      const pid_t worker = fork();
-      if (worker < 0) {
-        close(pfd[0]);
-        close(pfd[1]);
-      } else if (worker > 0) {
-        close(pfd[1]);
-        unsigned char code = 0;
-        ssize_t got;
-        do got = read(pfd[0], &code, 1);
-        while (got < 0 && errno == EINTR);
-        if (got == 1) _exit(code);
-        int st = 0;
-        while (waitpid(worker, &st, 0) < 0 && errno == EINTR) {
-        }
-        if (WIFEXITED(st) && WEXITSTATUS(st) != 0) return WEXITSTATUS(st);
-        fprintf(stderr, "zkpoa-setup: the worker process ended abnormally (%s %d)\n", WIFSIGNALED(st) ? "signal" : "status",
-                WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
-        return 1;
-      } else {
-        close(pfd[0]);
-        report_fd = pfd[1];
-        prctl(PR_SET_PDEATHSIG, SIGKILL);
-        if (getppid() != self) _exit(1);
-        zkpoa_setup_defer_host_frees(1);
-      }
-    }
-  }
-  auto leave = [&](int code) -> int {   // worker: hand the status over, release the caller's pipes, skip every teardown
-    if (report_fd < 0) return code;
-    fflush(stdout);
-    fflush(stderr);
-    const unsigned char b = (unsigned char)code;
-    (void)!write(report_fd, &b, 1);
-    close(STDIN_FILENO);
-    close(STDOUT_FILENO);
-    close(STDERR_FILENO);
-    _exit(code);
+  // `zkey new` / `zkey contribute` run in a worker process and this one leaves as soon as the key is renamed into place
+  // (csrc/worker_exit.hpp: a worker that has held ~100 GB of host arrays takes seconds to be dismantled).
+  zkpoa::WorkerExit we = zkpoa::WorkerExit::start(!check, "zkpoa-setup");
+  if (we.is_worker()) zkpoa_setup_defer_host_frees(1);
+  auto leave = [&](int code) -> int {
+    if (we.is_worker()) we.leave(code);
+    return code;
   };
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -151,7 +105,7 @@ int main(int argc, char** argv) {
     rc = contribute ? zkpoa_zkey_contribute(ctx, pos[0], pos[1], delta_p) : zkpoa_zkey_new(ctx, pos[0], pos[1], pos[2]);
   }
   if (rc != PROVER_OK) fprintf(stderr, "zkpoa-setup: %s\n", zkpoa_last_error(ctx));
-  if (report_fd < 0) zkpoa_context_destroy(ctx);
+  if (!we.is_worker()) zkpoa_context_destroy(ctx);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   if (rc == PROVER_OK && getenv("ZKPOA_VERBOSE") && !check)
     fprintf(stderr, "zkpoa-setup: %s written in %.2f s\n", pos[contribute ? 1 : 2],
