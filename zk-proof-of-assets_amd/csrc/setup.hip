@@ -35,6 +35,7 @@
 #include <exception>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -484,7 +485,48 @@ struct AtomicFile {
     parallel_ranges(len, 32ull << 20, [&](unsigned, uint64_t lo, uint64_t hi) { memcpy(dst + lo, static_cast<const char*>(p) + lo, hi - lo); });
     ok = munmap(m, lead + len) == 0 && fseeko(f, base + (off_t)len, SEEK_SET) == 0;
   }
+  // Absolute placement, for a file whose section offsets are known before their content: reserve() sizes it, put_at()
+  // may then be called from several threads for disjoint ranges in any order (small ranges: pwrite; large ones: the
+  // shared-mapping copy of write_large). The FILE stream is not used in this mode.
+  std::atomic<bool> placed_ok{true};
+  void reserve(uint64_t total) {
+    if (fflush(f) != 0 || ftruncate(fileno(f), (off_t)total) != 0) ok = false;
+  }
+  void put_at(uint64_t off, const void* p, uint64_t len) {
+    if (!len) return;
+    const int fd = fileno(f);
+    if (len < (64u << 20)) {
+      uint64_t done = 0;
+      while (done < len) {
+        const ssize_t w = pwrite(fd, static_cast<const char*>(p) + done, len - done, (off_t)(off + done));
+        if (w <= 0) {
+          placed_ok = false;
+          return;
+        }
+        done += (uint64_t)w;
+      }
+      return;
+    }
+    const uint64_t map_off = off & ~4095ull, lead = off - map_off;
+    void* m = mmap(nullptr, lead + len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_off);
+    if (m == MAP_FAILED) {
+      uint64_t done = 0;
+      while (done < len) {
+        const ssize_t w = pwrite(fd, static_cast<const char*>(p) + done, len - done, (off_t)(off + done));
+        if (w <= 0) {
+          placed_ok = false;
+          return;
+        }
+        done += (uint64_t)w;
+      }
+      return;
+    }
+    char* dst = static_cast<char*>(m) + lead;
+    parallel_ranges(len, 32ull << 20, [&](unsigned, uint64_t lo, uint64_t hi) { memcpy(dst + lo, static_cast<const char*>(p) + lo, hi - lo); });
+    if (munmap(m, lead + len) != 0) placed_ok = false;
+  }
   void commit() {
+    ok = ok && placed_ok.load();
     ok = (fclose(f) == 0) && ok;
     f = nullptr;
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
@@ -774,19 +816,140 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
   }
   phase("entry lists built");
   const uint64_t m = r.nWires;
-  UVec<uint8_t> secA, secB1, secB2, secK;
+  // ---- the file: sections 1-10 in the order snarkjs numbers them. Every length follows from the header and the term
+  // counts, so the file is sized now and each section is put at its place when it is ready: the host's own sections
+  // (header, coefficients, H) by a side thread WHILE the device computes the others.
+  const uint64_t nCoefs = r.A.size() + r.B.size() + r.nPublic + 1;
+  if (nCoefs > 0xffffffffull) throw SetupError("more than 2^32 coefficients");
+  const uint64_t kS2 = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128, icb = ((uint64_t)r.nPublic + 1) * 64;
+  const uint64_t sec_len[11] = {0, 4, kS2, icb, 4 + nCoefs * 44, m * 64, m * 64, m * 128, (m - r.nPublic - 1) * 64, n * 64, 64 + 4};
+  uint64_t sec_off[11], total_out = 12;
+  for (uint32_t t = 1; t <= 10; t++) {
+    sec_off[t] = total_out + 12;
+    total_out += 12 + sec_len[t];
+  }
+  AtomicFile fo(zkey_path);
+  fo.reserve(total_out);
+  auto put_section = [&](uint32_t id, const void* p, uint64_t len) {
+    if (len != sec_len[id]) throw SetupError("internal: section " + std::to_string(id) + " has an unexpected size");
+    fo.put_at(sec_off[id] - 12, &id, 4);
+    fo.put_at(sec_off[id] - 8, &len, 8);
+    fo.put_at(sec_off[id], p, len);
+  };
+  std::exception_ptr host_err;
+  double host_ms = 0;
+  std::thread host_sections([&] {
+    try {
+      struct timespec h0, h1;
+      clock_gettime(CLOCK_MONOTONIC, &h0);
+      const uint32_t hdr[2] = {1, 10};
+      fo.put_at(0, "zkey", 4);
+      fo.put_at(4, hdr, 8);
+      const uint32_t one_u32 = 1;   // section 1: protocol id 1 = groth16
+      put_section(1, &one_u32, 4);
+      std::vector<uint8_t> s2, s10(64 + 4, 0);
+      put32(s2, 32);
+      s2.insert(s2.end(), (const uint8_t*)HFqParams::P, (const uint8_t*)HFqParams::P + 32);
+      put32(s2, 32);
+      s2.insert(s2.end(), (const uint8_t*)HFrParams::P, (const uint8_t*)HFrParams::P + 32);
+      put32(s2, r.nWires);
+      put32(s2, r.nPublic);
+      put32(s2, (uint32_t)n);
+      uint8_t g1[64], g2[128];
+      h_affine_to_bytes<HFq>(host_generator<HFq>(), g1);
+      h_affine_to_bytes<HFq2>(host_generator<HFq2>(), g2);
+      s2.insert(s2.end(), alpha1, alpha1 + 64);
+      s2.insert(s2.end(), beta1, beta1 + 64);
+      s2.insert(s2.end(), beta2, beta2 + 128);
+      s2.insert(s2.end(), g2, g2 + 128);   // gamma2 = the generator until a contribution changes delta
+      s2.insert(s2.end(), g1, g1 + 64);    // delta1
+      s2.insert(s2.end(), g2, g2 + 128);   // delta2
+      put_section(2, s2.data(), s2.size());
+      put_section(10, s10.data(), s10.size());
+      // coefficients: A and B terms per constraint, then the public rows; values scaled by R^2
+      UVec<uint8_t> s4(4 + nCoefs * 44);
+      {
+        const uint32_t nc32 = (uint32_t)nCoefs;
+        memcpy(s4.data(), &nc32, 4);
+      }
+      auto rec = [&](uint64_t at, uint32_t mtx, uint32_t c, uint32_t sgn, const uint8_t* coef) {
+        uint8_t* o = s4.data() + 4 + at * 44;
+        memcpy(o, &mtx, 4);
+        memcpy(o + 4, &c, 4);
+        memcpy(o + 8, &sgn, 4);
+        HFr v = HFr::from_bytes(coef).to_mont();   // limbs = coef * R
+        HFr w = v.to_mont();                       // limbs = coef * R^2
+        memcpy(o + 12, w.l, 32);
+      };
+      // constraint ranges in parallel: a range starts at the first A / B term of its first constraint, and its records
+      // start at the count of A and B terms before that
+      parallel_ranges(r.nConstraints, 1u << 14, [&](unsigned, uint64_t c0, uint64_t c1) {
+        auto first = [&](const UVec<Term>& v, uint32_t c) {
+          return (size_t)(std::lower_bound(v.begin(), v.end(), c, [](const Term& t, uint32_t key) { return t.c < key; }) - v.begin());
+        };
+        size_t ia = first(r.A, (uint32_t)c0), ib = first(r.B, (uint32_t)c0);
+        uint64_t at = ia + ib;
+        for (uint32_t c = (uint32_t)c0; c < (uint32_t)c1; c++) {
+          for (; ia < r.A.size() && r.A[ia].c == c; ia++) rec(at++, 0, c, r.A[ia].s, r.A[ia].coef);
+          for (; ib < r.B.size() && r.B[ib].c == c; ib++) rec(at++, 1, c, r.B[ib].s, r.B[ib].coef);
+        }
+      });
+      {
+        const uint8_t one[32] = {1};
+        for (uint32_t i = 0; i <= r.nPublic; i++) rec(r.A.size() + r.B.size() + i, 0, r.nConstraints + i, i, one);
+      }
+      put_section(4, s4.data(), s4.size());
+      UVec<uint8_t> s9(n * 64);
+      parallel_ranges(n, 1u << 18, [&](unsigned, uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
+      });
+      put_section(9, s9.data(), s9.size());
+      clock_gettime(CLOCK_MONOTONIC, &h1);
+      host_ms = (h1.tv_sec - h0.tv_sec) * 1e3 + (h1.tv_nsec - h0.tv_nsec) / 1e6;
+    } catch (...) {
+      host_err = std::current_exception();
+    }
+  });
+  // a point section is handed to a writer thread as soon as it is back from the device: it goes into the file while the
+  // device works on the next one
+  std::vector<std::thread> writers;
+  std::mutex werr_mutex;
+  std::exception_ptr write_err;
+  auto write_async = [&](uint32_t id, const uint8_t* p, uint64_t len) {
+    writers.emplace_back([&, id, p, len] {
+      try {
+        put_section(id, p, len);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(werr_mutex);
+        if (!write_err) write_err = std::current_exception();
+      }
+    });
+  };
+  struct Joiner {   // (the device stage below may throw: the side threads are joined whatever happens)
+    std::thread& t;
+    std::vector<std::thread>& w;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+      for (auto& x : w)
+        if (x.joinable()) x.join();
+    }
+  } joiner{host_sections, writers};
+  UVec<uint8_t> secA, secB1, secB2, secK;   // (alive until every writer has been joined)
   {
     DevArr dL1(n * 64);
     dL1.up(L1.data(), L1.size());
     dev_check_coords(ctx, dL1.p, 2 * n, "ptau tau*G1 (Lagrange)");
     secA = run_accumulate<Fq>(ctx, dL1, n, eA, m);
+    write_async(5, secA.data(), secA.size());
     secB1 = run_accumulate<Fq>(ctx, dL1, n, eB, m);
+    write_async(6, secB1.data(), secB1.size());
   }
   {
     DevArr dL2(n * 128);
     dL2.up(L2.data(), L2.size());
     dev_check_coords(ctx, dL2.p, 4 * n, "ptau tau*G2 (Lagrange)");
     secB2 = run_accumulate<Fq2>(ctx, dL2, n, eB, m);
+    write_async(7, secB2.data(), secB2.size());
   }
   {
     DevArr dK(3 * n * 64);
@@ -796,83 +959,16 @@ void zkey_new(zkpoa_context* ctx, const char* r1cs_path, const char* ptau_path, 
     dev_check_coords(ctx, dK.p, 4 * n, "ptau alpha*tau*G1 / beta*tau*G1 (Lagrange)");
     secK = run_accumulate<Fq>(ctx, dK, 3 * n, eK, m);
   }
-
   phase("point sections (upload, device, download)");
-  // ---- the file: sections 1-10 in the order snarkjs numbers them
-  std::vector<uint8_t> s2, s10(64 + 4, 0);
-  UVec<uint8_t> s4, s9(n * 64);
-  put32(s2, 32);
-  s2.insert(s2.end(), (const uint8_t*)HFqParams::P, (const uint8_t*)HFqParams::P + 32);
-  put32(s2, 32);
-  s2.insert(s2.end(), (const uint8_t*)HFrParams::P, (const uint8_t*)HFrParams::P + 32);
-  put32(s2, r.nWires);
-  put32(s2, r.nPublic);
-  put32(s2, (uint32_t)n);
-  uint8_t g1[64], g2[128];
-  h_affine_to_bytes<HFq>(host_generator<HFq>(), g1);
-  h_affine_to_bytes<HFq2>(host_generator<HFq2>(), g2);
-  s2.insert(s2.end(), alpha1, alpha1 + 64);
-  s2.insert(s2.end(), beta1, beta1 + 64);
-  s2.insert(s2.end(), beta2, beta2 + 128);
-  s2.insert(s2.end(), g2, g2 + 128);   // gamma2 = the generator until a contribution changes delta
-  s2.insert(s2.end(), g1, g1 + 64);    // delta1
-  s2.insert(s2.end(), g2, g2 + 128);   // delta2
-  // coefficients: A and B terms per constraint, then the public rows; values scaled by R^2
-  const uint64_t nCoefs = r.A.size() + r.B.size() + r.nPublic + 1;
-  if (nCoefs > 0xffffffffull) throw SetupError("more than 2^32 coefficients");
-  s4.alloc(4 + nCoefs * 44);
-  {
-    const uint32_t nc32 = (uint32_t)nCoefs;
-    memcpy(s4.data(), &nc32, 4);
-  }
-  auto rec = [&](uint64_t at, uint32_t mtx, uint32_t c, uint32_t sgn, const uint8_t* coef) {
-    uint8_t* o = s4.data() + 4 + at * 44;
-    memcpy(o, &mtx, 4);
-    memcpy(o + 4, &c, 4);
-    memcpy(o + 8, &sgn, 4);
-    HFr v = HFr::from_bytes(coef).to_mont();   // limbs = coef * R
-    HFr w = v.to_mont();                       // limbs = coef * R^2
-    memcpy(o + 12, w.l, 32);
-  };
-  // constraint ranges in parallel: a range starts at the first A / B term of its first constraint, and its records
-  // start at the count of A and B terms before that
-  parallel_ranges(r.nConstraints, 1u << 14, [&](unsigned, uint64_t c0, uint64_t c1) {
-    auto first = [&](const UVec<Term>& v, uint32_t c) {
-      return (size_t)(std::lower_bound(v.begin(), v.end(), c, [](const Term& t, uint32_t key) { return t.c < key; }) - v.begin());
-    };
-    size_t ia = first(r.A, (uint32_t)c0), ib = first(r.B, (uint32_t)c0);
-    uint64_t at = ia + ib;
-    for (uint32_t c = (uint32_t)c0; c < (uint32_t)c1; c++) {
-      for (; ia < r.A.size() && r.A[ia].c == c; ia++) rec(at++, 0, c, r.A[ia].s, r.A[ia].coef);
-      for (; ib < r.B.size() && r.B[ib].c == c; ib++) rec(at++, 1, c, r.B[ib].s, r.B[ib].coef);
-    }
-  });
-  {
-    const uint8_t one[32] = {1};
-    for (uint32_t i = 0; i <= r.nPublic; i++) rec(r.A.size() + r.B.size() + i, 0, r.nConstraints + i, i, one);
-  }
-  phase("coefficient section");
-  parallel_ranges(n, 1u << 18, [&](unsigned, uint64_t lo, uint64_t hi) {
-    for (uint64_t i = lo; i < hi; i++) memcpy(&s9[i * 64], &Hs[(2 * i + 1) * 64], 64);   // odd points of the 2n basis
-  });
-  const size_t icb = ((size_t)r.nPublic + 1) * 64;
-  struct Out { uint32_t id; const uint8_t* p; uint64_t len; };
-  const uint32_t one_u32 = 1;   // section 1: protocol id 1 = groth16
-  const Out outs[] = {{1, (const uint8_t*)&one_u32, 4}, {2, s2.data(), s2.size()}, {3, secK.data(), icb},
-                      {4, s4.data(), s4.size()}, {5, secA.data(), secA.size()}, {6, secB1.data(), secB1.size()},
-                      {7, secB2.data(), secB2.size()}, {8, secK.data() + icb, secK.size() - icb},
-                      {9, s9.data(), s9.size()}, {10, s10.data(), s10.size()}};
-  AtomicFile fo(zkey_path);
-  fo.write("zkey", 4);
-  const uint32_t hdr[2] = {1, 10};
-  fo.write(hdr, 8);
-  for (const Out& o : outs) {
-    fo.write(&o.id, 4);
-    fo.write(&o.len, 8);
-    fo.write_large(o.p, o.len);
-  }
+  put_section(3, secK.data(), icb);
+  put_section(8, secK.data() + icb, secK.size() - icb);
+  host_sections.join();
+  for (auto& x : writers) x.join();
+  if (host_err) std::rethrow_exception(host_err);
+  if (write_err) std::rethrow_exception(write_err);
+  if (verbose) fprintf(stderr, "zkpoa: zkey new: (header, coefficient and H sections built and written by a side thread meanwhile: %.1f ms)\n", host_ms);
   fo.commit();
-  phase("zkey written");
+  phase("last sections written, key renamed into place");
 }
 
 // ---- `snarkjs wtns check <circuit.r1cs> <witness.wtns>` (g16_verify.sh:205-210) ---------------------------------------------
