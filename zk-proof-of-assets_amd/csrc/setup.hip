@@ -1091,21 +1091,49 @@ void zkey_contribute(zkpoa_context* ctx, const char* in_path, const char* out_pa
     }
     return out;
   };
-  const UVec<uint8_t> s8 = scaled(secs[8]), s9 = scaled(secs[9]);
+  // the output is sized up front (the section lengths do not change): the sections that are copied as they are go into
+  // it from a side thread while the device scales C and H
   AtomicFile fo(out_path);   // temporary name + rename: in_path == out_path is fine (the mapping keeps the old inode)
-  fo.write("zkey", 4);
-  const uint32_t hdr[2] = {1, 10};
-  fo.write(hdr, 8);
+  uint64_t off_of[11], total_out = 12;
   for (uint32_t t = 1; t <= 10; t++) {
-    const uint8_t* p = fi.p + secs[t].off;
-    uint64_t len = secs[t].len;
-    if (t == 2) p = s2.data();
-    if (t == 8) p = s8.data();
-    if (t == 9) p = s9.data();
-    fo.write(&t, 4);
-    fo.write(&len, 8);
-    fo.write_large(p, len);
+    off_of[t] = total_out + 12;
+    total_out += 12 + secs[t].len;
   }
+  fo.reserve(total_out);
+  auto put_section = [&](uint32_t t, const uint8_t* p) {
+    const uint64_t len = secs[t].len;
+    fo.put_at(off_of[t] - 12, &t, 4);
+    fo.put_at(off_of[t] - 8, &len, 8);
+    fo.put_at(off_of[t], p, len);
+  };
+  std::exception_ptr copy_err;
+  std::thread copier([&] {
+    try {
+      const uint32_t hdr[2] = {1, 10};
+      fo.put_at(0, "zkey", 4);
+      fo.put_at(4, hdr, 8);
+      put_section(2, s2.data());
+      for (uint32_t t : {1u, 3u, 4u, 5u, 6u, 7u, 10u}) put_section(t, fi.p + secs[t].off);
+    } catch (...) {
+      copy_err = std::current_exception();
+    }
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{copier};
+  {
+    const UVec<uint8_t> s8 = scaled(secs[8]);
+    put_section(8, s8.data());
+  }
+  {
+    const UVec<uint8_t> s9 = scaled(secs[9]);
+    put_section(9, s9.data());
+  }
+  copier.join();
+  if (copy_err) std::rethrow_exception(copy_err);
   fo.commit();
 }
 
